@@ -1,0 +1,83 @@
+"""Synthetic posed RGB-D episode driver (replaces the Habitat simulator side, which is out of scope).
+
+Spec: SURVEY.md section 8(d) / BASELINE.md section 3 -- seed 0; RGB uint8 (B,224,224,3) uniform;
+depth fp32 (B,224,224,1) ~ U(0.05,0.5) with 1 % exact zeros (x10 -> metres); pose x,z ~ U(-2,2),
+y = 0, heading ~ U(0,2pi), advancing 0.25 m along the heading and turning U(-30,30) deg per step;
+`patch_segm` = 4x4 blocks of 6x6 patches with a seeded label permutation (16 segments), already in
+the dense-relabelled form `get_patch_segm` produces (VLN-FF:416-420).
+
+Everything is generated with numpy's PCG64 on the host so the CPU oracle and the GPU path see
+bit-identical inputs on any machine.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+INSTRUCTION_64 = (
+    "walk forward past the kitchen counter and turn left at the dining table then continue down the "
+    "hallway until you reach the second door on your right enter the bedroom and walk around the bed "
+    "to the window then turn right and stop next to the wooden dresser beside the small reading lamp "
+    "and wait there facing the large mirror on the far wall of the room near the open closet door now"
+)
+
+
+@dataclass
+class Frame:
+    rgb: np.ndarray          # (B,h,w,3) uint8
+    depth: np.ndarray        # (B,H,W,1) float32 in [0,1]
+    positions: List[np.ndarray]  # habitat (x,y,z) per env, float64 like habitat's agent state
+    headings: List[float]
+    patch_segm: np.ndarray   # (B,1,24,24) int64 dense labels 0..n-1
+
+
+class SyntheticEpisodes:
+    def __init__(self, batch_size: int = 8, seed: int = 0, image_hw: int = 224, depth_hw: int = 224,
+                 n_blocks: int = 4, grid: int = 24, stationary: bool = False, wall: float | None = None):
+        self.B = batch_size
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+        self.image_hw, self.depth_hw, self.grid, self.n_blocks = image_hw, depth_hw, grid, n_blocks
+        self.stationary, self.wall = stationary, wall
+        self.pos = [np.array([self.rng.uniform(-2, 2), 0.0, self.rng.uniform(-2, 2)], np.float64) for _ in range(batch_size)]
+        self.head = [float(self.rng.uniform(0, 2 * math.pi)) for _ in range(batch_size)]
+        self.t = 0
+
+    def _segm(self) -> np.ndarray:
+        g, nb = self.grid, self.n_blocks
+        blk = g // nb
+        out = np.zeros((self.B, 1, g, g), np.int64)
+        for b in range(self.B):
+            perm = self.rng.permutation(nb * nb)
+            lab = perm.reshape(nb, nb)
+            out[b, 0] = np.kron(lab, np.ones((blk, blk), np.int64))
+        return out
+
+    def next(self) -> Frame:
+        B, rng = self.B, self.rng
+        rgb = rng.integers(0, 256, size=(B, self.image_hw, self.image_hw, 3), dtype=np.uint8)
+        if self.wall is None:
+            depth = rng.uniform(0.05, 0.5, size=(B, self.depth_hw, self.depth_hw, 1)).astype(np.float32)
+        else:  # flat wall `wall` metres away (x10 scaling) -> every stored patch is re-observed
+            depth = np.full((B, self.depth_hw, self.depth_hw, 1), self.wall / 10.0, np.float32)
+        zeros = rng.random(size=depth.shape) < 0.01
+        depth[zeros] = 0.0
+        fr = Frame(rgb=rgb, depth=depth, positions=[p.copy() for p in self.pos], headings=list(self.head),
+                   patch_segm=self._segm())
+        if not self.stationary:
+            for b in range(B):
+                h = self.head[b]
+                # habitat: heading CCW about +y, forward = -z rotated by heading
+                self.pos[b][0] += -0.25 * math.sin(h)
+                self.pos[b][2] += -0.25 * math.cos(h)
+                self.head[b] = float((h + math.radians(rng.uniform(-30, 30))) % (2 * math.pi))
+        self.t += 1
+        return fr
+
+
+def nearest_resize_indices(src: int, dst: int) -> np.ndarray:
+    """cv2.resize(INTER_NEAREST) source index rule (VLN-POL:339): floor(dst_i * src/dst), clamped."""
+    idx = np.floor(np.arange(dst) * (src / dst)).astype(np.int64)
+    return np.minimum(idx, src - 1)

@@ -1,0 +1,212 @@
+"""Container-only harness that imports the REFERENCE's own Feature_Fields / VisionTransformer.
+
+TEST INFRASTRUCTURE -- never imported by the product (`dynam3d_amd/`), by `bench.py`'s GPU leg
+or by any `-m gpu` test.  It exists to (a) generate the golden vectors committed under
+`tests/golden/` (see `tests/golden/gen_golden.py`) and (b) validate `oracle/ff_oracle.py`
+against the real reference while `/root/reference` is mounted (this container only; the GPU box
+has no `/root/reference`).
+
+Nothing from the reference is copied: the files are loaded in place with
+`importlib.util.spec_from_file_location` after pre-seeding `sys.modules` with stubs for the
+un-installed third-party packages (recipe: SURVEY.md section 10).
+
+Stub semantics that DEFINE parity for un-vendored dependencies ("parity unpinned" upstream):
+  * torch_kdtree.build_kd_tree(points).query(q, nr_nns_searches=k)
+        -> brute force, ascending (dist^2, index); d2 = (dx*dx + dy*dy) + dz*dz in float32, stable
+           sort (torch_kdtree itself evaluates exact squared differences; SURVEY's cdist probe did not)
+  * tinycudann.Network -> bias-free MLP, LeakyReLU(0.01), see `TcnnStub`.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+REF_ROOT = os.environ.get("DYNAM3D_REFERENCE", "/root/reference")
+VLN_FF = os.path.join(REF_ROOT, "Dynam3D_VLN/vlnce_baselines/models/feature_fields.py")
+PRE_FF = os.path.join(REF_ROOT, "Dynam3D_Pretrain/src_3dff/models/feature_fields.py")
+CLIP_MODEL = os.path.join(REF_ROOT, "Dynam3D_VLN/vlnce_baselines/models/encoders/clip/model.py")
+
+
+def reference_available() -> bool:
+    return os.path.isfile(VLN_FF)
+
+
+# --------------------------------------------------------------------------------------------
+# stubs
+# --------------------------------------------------------------------------------------------
+class _BruteTree:
+    """Defines KNN parity: ascending (dist^2, idx), ties -> lowest index."""
+
+    def __init__(self, pts):
+        if isinstance(pts, np.ndarray):
+            pts = torch.from_numpy(pts)
+        # torch_kdtree copies the points when it builds the tree -> snapshot semantics.
+        self.pts = pts.detach().clone().float()
+
+    def query(self, q, nr_nns_searches=1):
+        if isinstance(q, np.ndarray):
+            q = torch.from_numpy(q)
+        q = q.float()
+        p = self.pts.to(q.device)
+        k = int(nr_nns_searches)
+        dx = q[:, None, 0] - p[None, :, 0]
+        dy = q[:, None, 1] - p[None, :, 1]
+        dz = q[:, None, 2] - p[None, :, 2]
+        d = (dx * dx + dy * dy) + dz * dz          # one rounding per op, fixed order
+        ds, idx = torch.sort(d, dim=-1, stable=True)  # ascending (dist^2, index)
+        return ds[:, :k].contiguous(), idx[:, :k].contiguous()
+
+
+class TcnnStub(torch.nn.Module):
+    """tinycudann.Network('CutlassMLP') stand-in: y = act(x W^T) per layer, no biases."""
+
+    def __init__(self, n_input_dims, n_output_dims, network_config, seed=1337):
+        super().__init__()
+        nh = int(network_config["n_hidden_layers"])
+        nn_ = int(network_config["n_neurons"])
+        dims = [n_input_dims] + [nn_] * nh + [n_output_dims]
+        self.act = network_config.get("activation", "None")
+        self.out_act = network_config.get("output_activation", "None")
+        self.weights = torch.nn.ParameterList(
+            [torch.nn.Parameter(torch.randn(dims[i + 1], dims[i]) * dims[i] ** -0.5) for i in range(len(dims) - 1)]
+        )
+
+    @staticmethod
+    def _apply(name, x):
+        if name in ("LeakyReLU", "leakyrelu"):
+            return torch.nn.functional.leaky_relu(x, 0.01)
+        if name in ("ReLU", "relu"):
+            return torch.relu(x)
+        if name in ("None", "none", None):
+            return x
+        raise NotImplementedError(name)
+
+    def forward(self, x):
+        h = x
+        for i, w in enumerate(self.weights):
+            h = h.to(w.dtype) @ w.t()
+            h = self._apply(self.act if i < len(self.weights) - 1 else self.out_act, h)
+        return h
+
+
+class _NdArrayEq(np.ndarray):
+    """numpy>=2 raises on `arr == []`; the reference tests emptiness that way (VLN-FF:557,567)."""
+
+    def __eq__(self, other):
+        if isinstance(other, list) and len(other) == 0:
+            return False
+        return np.ndarray.__eq__(self, other)
+
+    __hash__ = None
+
+
+class _StoreList(list):
+    def __setitem__(self, k, v):
+        if isinstance(v, np.ndarray) and not isinstance(v, _NdArrayEq):
+            v = v.view(_NdArrayEq)
+        list.__setitem__(self, k, v)
+
+
+def _install_stubs(pkg: str):
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("torch_kdtree", build_kd_tree=lambda pts, *a, **k: _BruteTree(pts))
+    mod("open3d")
+    import argparse
+
+    mod("configargparse", ArgumentParser=argparse.ArgumentParser)
+    p = mod(pkg)
+    p.__path__ = []
+    pm = mod(pkg + ".models")
+    pm.__path__ = []
+
+    class FastSAM:  # noqa: D401 - dummy
+        def __init__(self, *a, **k):
+            pass
+
+    class FastSAMPrompt:
+        def __init__(self, *a, **k):
+            pass
+
+    mod(pkg + ".models.fastsam", FastSAM=FastSAM, FastSAMPrompt=FastSAMPrompt)
+    mod("tinycudann", Network=TcnnStub)
+    torch.cuda.get_device_properties = lambda *a, **k: SimpleNamespace(total_memory=64 * 1024 ** 3)
+    torch.cuda.memory_allocated = lambda *a, **k: 0
+
+
+def load_ref_module(which: str = "vln"):
+    path, pkg = (VLN_FF, "vlnce_baselines") if which == "vln" else (PRE_FF, "src_3dff")
+    _install_stubs(pkg)
+    argv = sys.argv
+    sys.argv = ["x"]
+    try:
+        spec = importlib.util.spec_from_file_location("ref_ff_" + which, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+    finally:
+        sys.argv = argv
+    return m
+
+
+def load_ref_clip():
+    spec = importlib.util.spec_from_file_location("ref_clip_model", CLIP_MODEL)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+class RefFeatureFields:
+    """Drives the reference's VLN `Feature_Fields` on CPU with a synthetic segmentation."""
+
+    def __init__(self, batch_size: int, state_dict=None, which="vln"):
+        self.mod = load_ref_module(which)
+        argv = sys.argv
+        sys.argv = ["x"]
+        try:
+            self.F = self.mod.Feature_Fields(batch_size=batch_size, device="cpu").eval()
+        finally:
+            sys.argv = argv
+        if state_dict is not None:
+            missing, unexpected = self.F.load_state_dict(state_dict, strict=False)
+            assert not [k for k in missing if "FastSAM" not in k], missing
+        self._segm = None
+        self.F.get_patch_segm = self._get_patch_segm
+        self.reset(batch_size)
+
+    def _get_patch_segm(self, imgs, **kw):
+        s = self._segm
+        assert s is not None and s.shape[0] == len(imgs)
+        return s.clone()
+
+    def _wrap_stores(self):
+        for name in ("global_patch_position", "global_patch_fts", "global_patch_scales", "global_patch_directions"):
+            setattr(self.F, name, _StoreList(getattr(self.F, name)))
+
+    def reset(self, batch_size):
+        self.F.reset(batch_size)
+        self.F.initialize_camera_setting(90.0, 90.0)
+        self._wrap_stores()
+
+    @torch.no_grad()
+    def step(self, depth_full, depth24, grid_fts, patch_segm, positions, headings, num_of_views=1, delete=True):
+        """depth_full (B,V,Hd,Wd) f32 metres torch; depth24 (B,V,576) np f32 metres;
+        grid_fts (B,V,576,768) np f32; patch_segm (B*V,1,24,24) int64 torch; positions list of np(3,) habitat."""
+        F = self.F
+        B = F.batch_size
+        if delete:
+            F.delete_old_features_from_camera_frustum(depth_full, positions, headings, num_of_views=num_of_views)
+        self._segm = patch_segm
+        img = np.zeros((B, num_of_views, 8, 8, 3), np.uint8)
+        F.update_feature_fields(depth24, grid_fts, batch_image=img, batch_position=positions,
+                                batch_heading=headings, num_of_views=num_of_views)
+        return F.get_environment_features(positions, headings)

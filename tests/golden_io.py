@@ -1,0 +1,50 @@
+"""Shared helpers for golden fixtures: seed -> inputs regeneration and ragged packing.
+The FF boundary is pinned on already-preprocessed inputs: depth24 / depth_full in
+metres, CLIP grid features, dense patch_segm, habitat pose."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from dynam3d_amd.synthetic import SyntheticEpisodes
+from oracle import geometry as G
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TRAJ_CASES = {
+    # name: episode generator settings
+    "walk": dict(B=2, steps=7, seed=1, grid_seed=5, stationary=False, wall=None, depth_hw=224),
+    "wall": dict(B=2, steps=5, seed=2, grid_seed=6, stationary=True, wall=2.0, depth_hw=64),
+}
+
+
+def traj_inputs(case):
+    B = case["B"]
+    ep = SyntheticEpisodes(B, seed=case["seed"], stationary=case["stationary"], wall=case["wall"],
+                           depth_hw=case["depth_hw"], image_hw=32)
+    rng = np.random.default_rng(case["grid_seed"])
+    for _ in range(case["steps"]):
+        fr = ep.next()
+        dfull = G.preprocess_depth(fr.depth)[..., 0]
+        d24 = G.preprocess_depth(G.downsample_depth_nearest(fr.depth)).reshape(B, 1, 576)
+        grid = rng.standard_normal((B, 1, 576, 768)).astype(np.float32)
+        yield dict(depth_full=dfull.reshape(B, 1, *dfull.shape[1:]).copy(), depth24=d24, grid=grid,
+                   patch_segm=fr.patch_segm, positions=[p.tolist() for p in fr.positions], headings=list(fr.headings),
+                   depth_raw=fr.depth, rgb=fr.rgb)
+
+
+def pack_ragged(arrs):
+    off = np.zeros(len(arrs) + 1, np.int64)
+    for i, a in enumerate(arrs):
+        off[i + 1] = off[i] + len(a)
+    flat = np.concatenate([np.asarray(a, np.int64) for a in arrs]) if arrs else np.zeros(0, np.int64)
+    return flat, off
+
+
+def unpack_ragged(flat, off):
+    return [flat[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
