@@ -1,0 +1,385 @@
+"""`Feature_Fields` -- MI355X-native drop-in for the reference's online patch -> instance -> zone
+memory (Dynam3D_VLN/vlnce_baselines/models/feature_fields.py:119-862, "VLN-FF").
+
+Same public surface (reset / pop / initialize_camera_setting / delete_old_features_from_camera_frustum
+/ update_feature_fields / get_environment_features / get_patch_3d_info / delete_feature_fields,
+attributes batch_size, args, keep_target_waypoint, history_actions) but a different architecture:
+
+  * all patch / instance / zone stores are DEVICE-RESIDENT SoA pools (ops.Pools) sized for the
+    episode; nothing is copied to the host except a few hundred bytes of indices per step;
+  * every environment of the batch is processed by the same kernel launches (the reference loops
+    over environments, views and segments in Python);
+  * float work = HIP kernels (ops.HipOps -> libdynam3d_hip.so) + batched dense encoders
+    (ff_dense.FFDense); the dict / id bookkeeping is the C++ state machine behind d3d_ff_*
+    (csrc/ff_state.cpp), which only ever sees integers.
+
+`compat='reference'` (default) reproduces the reference's id/row quirks so golden
+trajectories match; `compat='fixed'` keeps id == row.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .ops import FTS, CameraTables, Pools, make_pose
+from ._ffstate import FFState
+from .ff_dense import FFDense
+
+K_MAX_CHOICES = (1, 2, 4, 8)
+
+
+def _args_namespace():
+    # VLN-FF:22-46 defaults (fts_dim is declared float there; kept numeric-compatible)
+    return SimpleNamespace(input_hfov=90.0, input_vfov=90.0, input_height=24, input_width=24, fts_dim=768,
+                           zone_x_length=2.0, zone_y_length=2.0, zone_z_length=2.0, deleted_frustum_distance=3.0,
+                           num_proposal_instances=2)
+
+
+class Feature_Fields:
+    def __init__(self, batch_size: int = 1, device="cuda", state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 compat: str = "reference", max_steps: int = 64, max_views: int = 1, m_cap: int = 4096, z_cap: int = 2048,
+                 ops=None, segmenter=None):
+        self.device = torch.device(device)
+        self.args = _args_namespace()
+        if ops is None:
+            from .ops import HipOps
+            ops = HipOps()                      # raises if libdynam3d_hip.so is missing: no CPU fallback
+        self.ops = ops
+        self.compat = compat
+        self.max_steps, self.max_views = max_steps, max_views
+        self._m_cap, self._z_cap = m_cap, z_cap
+        self.segmenter = segmenter              # callable(batch_image) -> (N,1,24,24) dense int labels (a6)
+        self.dense: Optional[FFDense] = None
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+        self.state = FFState(ops.lib, compat, self.P, self.args.num_proposal_instances)
+        self._cam: Optional[CameraTables] = None
+        self.pools: Optional[Pools] = None
+        self.reset(batch_size)
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def P(self):
+        return self.args.input_height * self.args.input_width
+
+    @property
+    def cell_len(self):
+        return (float(self.args.zone_x_length), float(self.args.zone_y_length), float(self.args.zone_z_length))
+
+    def load_state_dict(self, sd, strict: bool = True):
+        sd = {k: v for k, v in sd.items() if not k.startswith("FastSAM") and not k.startswith("nerf_")}
+        self.dense = FFDense(sd, self.device, n_head=int(self.args.fts_dim) // 64)
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        return list(self.dense.w.values()) if self.dense else []
+
+    # ---- lifecycle (VLN-FF:186-240) ------------------------------------------------------------
+    def reset(self, batch_size: int = 1):
+        self.batch_size = batch_size
+        self.state.reset(batch_size)
+        tomb = [int(math.floor(-10000.0 / L)) for L in self.cell_len]
+        self.state.set_tomb_cell(tomb)
+        n_cap = self.P * self.max_views * self.max_steps
+        if self.pools is None or self.pools.rows_pos.shape[0] < batch_size or self.pools.n_cap != n_cap:
+            self.pools = Pools.allocate(batch_size, n_cap, self._m_cap, self._z_cap, self.device)
+        self.slots: List[int] = list(range(batch_size))
+        self.keep_target_waypoint = [None for _ in range(batch_size)]
+        self.history_actions = [["none\n"] * 4 for _ in range(batch_size)]      # per-row lists
+        self._tree_slots = [0] * batch_size
+
+    def pop(self, index: int):
+        self.batch_size -= 1
+        self.state.pop(index)
+        self.slots.pop(index)
+        self.keep_target_waypoint.pop(index)
+        self.history_actions.pop(index)
+        self._tree_slots.pop(index)
+
+    def initialize_camera_setting(self, hfov, vfov):
+        self.args.input_hfov, self.args.input_vfov = hfov, vfov
+        self._cam = None
+
+    def delete_feature_fields(self):
+        self.pools = None
+        self.state.reset(0)
+        self.slots, self.keep_target_waypoint, self.history_actions, self._tree_slots = [], [], [], []
+        self.batch_size = 0
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def _camera(self) -> CameraTables:
+        if self._cam is None:
+            self._cam = CameraTables.build(self.args.input_height, self.args.input_width, self.args.input_hfov,
+                                           self.args.input_vfov, self.device)
+        return self._cam
+
+    def _i32(self, a) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(self.device, non_blocking=True)
+
+    def _f32(self, a) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device, non_blocking=True)
+
+    def _dev(self, x, dtype=torch.float32) -> torch.Tensor:
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        return x.to(self.device, dtype=dtype, non_blocking=True).contiguous()
+
+    def _poses(self, positions, headings, envs, view_offset=0.0) -> torch.Tensor:
+        return self._f32(np.stack([make_pose(positions[e], view_offset + float(headings[e])) for e in envs]))
+
+    def _grow_rows(self, need: int):
+        if need <= self.pools.n_cap:
+            return
+        new_cap = max(need, self.pools.n_cap * 2)
+        old = self.pools
+        S = old.rows_pos.shape[0]
+        new = Pools.allocate(S, new_cap, old.m_cap, old.z_cap, self.device)
+        n = old.n_cap
+        new.rows_pos[:, :n], new.rows_fts[:, :n], new.rows_dir[:, :n], new.rows_scale[:, :n] = old.rows_pos, old.rows_fts, old.rows_dir, old.rows_scale
+        new.inst_pos, new.inst_fts, new.tree_pos, new.zone_pos, new.zone_fts = old.inst_pos, old.inst_fts, old.tree_pos, old.zone_pos, old.zone_fts
+        self.pools = new
+
+    def _snapshot_tree(self):
+        # kd-tree rebuild (VLN-FF:396, 815): the tree owns a COPY of the instance centres
+        self.pools.tree_pos.copy_(self.pools.inst_pos)
+        for e in range(self.batch_size):
+            self._tree_slots[e] = self.state.end_view(e)
+
+    # ---- a4 + cascade (VLN-FF:329-396) ---------------------------------------------------------------
+    @torch.no_grad()
+    def delete_old_features_from_camera_frustum(self, batch_depth, batch_position=None, batch_heading=None,
+                                                batch_camera_intrinsic=None, batch_extrinsic=None, num_of_views=1):
+        if batch_extrinsic is not None:
+            raise NotImplementedError("intrinsics/extrinsics (non-Habitat datasets) path: SURVEY.md 8f-2")
+        depth = self._dev(batch_depth)                                  # (B,V,Hd,Wd) metres
+        B, st, pools = self.batch_size, self.state, self.pools
+        Hd, Wd = depth.shape[-2], depth.shape[-1]
+        a = self.args
+        intr = (float(np.float32(Wd / np.tan(np.deg2rad(a.input_hfov) / 2.0) / 2.0)),
+                float(np.float32(Hd / np.tan(np.deg2rad(a.input_vfov) / 2.0) / 2.0)), Wd / 2.0, Hd / 2.0)
+        for ix in range(num_of_views):
+            envs = [e for e in range(B) if st.count(e, st.ROWS) > 0]
+            if not envs:
+                continue
+            n_rows = [st.count(e, st.ROWS) for e in envs]
+            pose = self._poses(batch_position, batch_heading, envs)        # no per-view offset (VLN-FF:347)
+            slot = self._i32([self.slots[e] for e in envs])
+            hits = torch.empty((len(envs), max(n_rows)), dtype=torch.int32, device=self.device)
+            n_hits = torch.zeros((len(envs),), dtype=torch.int32, device=self.device)
+            d_ix = depth[envs, ix].contiguous() if len(envs) != B else depth[:, ix].contiguous()
+            self.ops.frustum_cull(pools, slot, self._i32(n_rows), max(n_rows), d_ix, pose, intr, 0.0,
+                                  float(a.deleted_frustum_distance), 0.1, hits, n_hits)
+            n_hits_h = n_hits.cpu().numpy()                                  # sync #1: a few ints
+            mx = int(n_hits_h.max())
+            if mx == 0:
+                continue
+            hits_h = hits[:, :mx].cpu().numpy()
+            di_s, di_r, dz_s, dz_r = [], [], [], []
+            for j, e in enumerate(envs):
+                dead_i, dead_z = st.apply_hits(e, hits_h[j, :n_hits_h[j]])
+                di_s += [self.slots[e]] * len(dead_i); di_r += dead_i.tolist()
+                dz_s += [self.slots[e]] * len(dead_z); dz_r += dead_z.tolist()
+            if di_r:                                                          # VLN-FF:378-379
+                s, r = self._i32(di_s), self._i32(di_r)
+                self.ops.fill_rows(pools.inst_pos, s, r, -10000.0)
+                self.ops.fill_rows(pools.inst_fts, s, r, 0.0)
+            if dz_r:                                                          # VLN-FF:392-393
+                s, r = self._i32(dz_s), self._i32(dz_r)
+                self.ops.fill_rows(pools.zone_pos, s, r, -10000.0)
+                self.ops.fill_rows(pools.zone_fts, s, r, 0.0)
+        self._snapshot_tree()
+
+    # ---- a6 contract ------------------------------------------------------------------------------------
+    def get_patch_segm(self, batch_image, **kw):
+        if self.segmenter is None:
+            raise NotImplementedError("no segmenter configured: pass patch_segm=... (dense int labels, (B*V,1,24,24)); "
+                                      "FastSAM itself is outside the hot path (SURVEY.md 8f-3)")
+        return self.segmenter(batch_image, **kw)
+
+    # ---- update_feature_fields (VLN-FF:493-815) ------------------------------------------------------------
+    @torch.no_grad()
+    def update_feature_fields(self, batch_depth, batch_grid_ft, batch_image=None, batch_position=None, batch_heading=None,
+                              batch_camera_intrinsic=None, batch_rot=None, batch_trans=None, depth_scale=1000.0,
+                              depth_trunc=1000.0, num_of_views=1, patch_segm=None):
+        if batch_camera_intrinsic is not None:
+            raise NotImplementedError("Open3D / intrinsics path (non-Habitat datasets): SURVEY.md 8f-2")
+        if self.dense is None:
+            raise RuntimeError("Feature_Fields has no weights: call load_state_dict first")
+        B, V, P, st, pools, ops = self.batch_size, num_of_views, self.P, self.state, self.pools, self.ops
+        K = self.args.num_proposal_instances
+        k_max = next(k for k in K_MAX_CHOICES if k >= K)
+        if patch_segm is None:
+            patch_segm = self.get_patch_segm(batch_image)
+        if isinstance(patch_segm, torch.Tensor):
+            patch_segm = patch_segm.cpu().numpy()
+        segm_all = np.asarray(patch_segm).reshape(B, V, P).astype(np.int32)
+        depth24 = self._dev(batch_depth).view(B, V, P)
+        if isinstance(batch_grid_ft, (list, tuple)):
+            batch_grid_ft = np.stack([np.asarray(g) for g in batch_grid_ft])
+        grid = batch_grid_ft if isinstance(batch_grid_ft, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(batch_grid_ft))
+        grid = grid.to(self.device)
+        if grid.dtype not in (torch.float16, torch.float32):
+            grid = grid.float()
+        grid = grid.view(B, V, P, FTS)
+        cam = self._camera()
+        envs = list(range(B))
+        slots_h = np.array([self.slots[e] for e in envs], np.int32)
+        slot = self._i32(slots_h)
+        self.last_debug = []
+        for ix in range(V):
+            self._grow_rows(max(st.count(e, st.ROWS) for e in envs) + P)
+            pools = self.pools
+            rb, k0, has_tree = zip(*[st.begin_view(e) for e in envs])
+            k0 = [k if t else 0 for k, t in zip(k0, has_tree)]
+            row_base = self._i32(rb)
+            pose = self._poses(batch_position, batch_heading, envs, view_offset=ix * (-math.pi / 6))   # VLN-FF:550
+            ops.unproject_append(depth24[:, ix].contiguous(), pose, slot, row_base, cam, pools)
+            ops.append_fts(grid[:, ix].contiguous(), slot, row_base, pools)
+
+            # ---- 2D instances of this frame: groups padded to n_max per env -------------------------
+            segm = segm_all[:, ix]
+            n_seg = segm.max(axis=1) + 1
+            n_max = int(n_seg.max())
+            order = np.argsort(segm, axis=1, kind="stable")                   # patches by (label, p)
+            counts = np.stack([np.bincount(segm[e], minlength=n_max) for e in envs])
+            if np.any((counts[np.arange(n_max)[None] < n_seg[:, None]]) == 0):
+                raise ValueError("patch_segm labels must be dense 0..n-1 (VLN-FF:416-420)")
+            tok_slot = np.repeat(slots_h, P)
+            tok_row = (np.asarray(rb, np.int32)[:, None] + order).reshape(-1).astype(np.int32)
+            grp_off = np.concatenate([[0], np.cumsum(counts.reshape(-1))]).astype(np.int32)
+            G = len(envs) * n_max
+            centroid, cell, geom7 = ops.group_stats7(pools, self._i32(tok_slot), self._i32(tok_row), self._i32(grp_off), G, self.cell_len)
+            tok_fts = ops.gather_fts(pools, self._i32(tok_slot), self._i32(tok_row))
+            valid_g = np.nonzero(counts.reshape(-1) > 0)[0]
+            new_fts_valid = self.dense.encode_patch_sets(tok_fts, geom7, counts.reshape(-1)[valid_g])
+            new_fts = torch.zeros((G, FTS), dtype=torch.float32, device=self.device)
+            new_fts.index_copy_(0, torch.from_numpy(valid_g).to(self.device), new_fts_valid)
+
+            # ---- KNN proposals + merge discriminator (VLN-FF:604-621) ------------------------------
+            ident = all(self.slots[e] == e for e in envs)
+            tree_pts = pools.tree_pos if ident else pools.tree_pos.index_select(0, slot.long()).contiguous()
+            d2, idx = ops.knn(tree_pts, pools.m_cap * 3, self._i32(self._tree_slots), centroid, n_max * 3,
+                              self._i32(n_seg), self._i32(k0), len(envs), n_max, k_max)
+            pair_e, pair_s, pair_j = [], [], []
+            for j_, e in enumerate(envs):
+                if k0[j_] > 0:
+                    ss, jj = np.meshgrid(np.arange(n_seg[j_]), np.arange(k0[j_]), indexing="ij")
+                    pair_e.append(np.full(ss.size, j_)); pair_s.append(ss.reshape(-1)); pair_j.append(jj.reshape(-1))
+            logits_full = torch.zeros((len(envs), n_max, k_max, 2), dtype=torch.float32, device=self.device)
+            if pair_e:
+                pe, ps_, pj = (torch.from_numpy(np.concatenate(x)).to(self.device) for x in (pair_e, pair_s, pair_j))
+                pair_inst = idx[pe, ps_, pj].contiguous()
+                pair_new = (pe * n_max + ps_).to(torch.int32).contiguous()
+                x = ops.merge_input(pools, new_fts, centroid, slot[pe].contiguous(), pair_inst, pair_new)
+                logits_full[pe, ps_, pj] = self.dense.merge_logits(x)
+            d2_h, idx_h, logits_h, cell_h = d2.cpu().numpy(), idx.cpu().numpy(), logits_full.cpu().numpy(), cell.cpu().numpy()  # sync #2
+
+            # ---- bookkeeping: new ids / merges ---------------------------------------------------------
+            new_s, new_r, new_src = [], [], []
+            m_tok_slot, m_tok_row, m_lens, m_slot, m_inst, m_env = [], [], [], [], [], []
+            dbg = []
+            for j_, e in enumerate(envs):
+                n = int(n_seg[j_])
+                cells_e = cell_h[j_ * n_max: j_ * n_max + n]
+                k_eff, seg_slot, dirty, doff, drows = st.plan_merge(e, segm[j_], n, k0[j_], k_max, d2_h[j_, :n], idx_h[j_, :n],
+                                                                    logits_h[j_, :n], cells_e)
+                dbg.append(dict(k_eff=k_eff, seg_slot=seg_slot.copy(), dirty=dirty.copy(), idx=idx_h[j_, :n].copy(),
+                                d2=d2_h[j_, :n].copy(), logits=logits_h[j_, :n].copy()))
+                for s in np.nonzero(seg_slot >= 0)[0]:
+                    new_s.append(self.slots[e]); new_r.append(int(seg_slot[s])); new_src.append(j_ * n_max + int(s))
+                for i, inst in enumerate(dirty):
+                    rows = drows[doff[i]:doff[i + 1]]
+                    m_tok_slot.append(np.full(len(rows), self.slots[e], np.int32)); m_tok_row.append(rows)
+                    m_lens.append(len(rows)); m_slot.append(self.slots[e]); m_inst.append(int(inst)); m_env.append(j_)
+            self.last_debug.append(dbg)
+            if max(st.count(e, st.SLOTS) for e in envs) > pools.m_cap:
+                raise RuntimeError("instance pool capacity exceeded (raise m_cap)")
+            if new_r:                                                        # VLN-FF:643-648
+                s, r, src = self._i32(new_s), self._i32(new_r), self._i32(new_src)
+                ops.scatter_rows(pools.inst_pos, s, r, centroid, src)
+                ops.scatter_rows(pools.inst_fts, s, r, new_fts, src)
+            dirty_cells = np.zeros((0, 3), np.int32)
+            if m_lens:                                                       # VLN-FF:662-688
+                ts, tr = self._i32(np.concatenate(m_tok_slot)), self._i32(np.concatenate(m_tok_row))
+                goff = self._i32(np.concatenate([[0], np.cumsum(m_lens)]))
+                gs, gi = self._i32(m_slot), self._i32(m_inst)
+                _, mcell, mgeom = ops.group_stats7(pools, ts, tr, goff, len(m_lens), self.cell_len, pools.inst_pos, gs, gi)
+                mfts = ops.gather_fts(pools, ts, tr)
+                merged = self.dense.encode_patch_sets(mfts, mgeom, m_lens)
+                ops.scatter_rows(pools.inst_fts, gs, gi, merged)
+                dirty_cells = mcell.cpu().numpy()                           # sync #3
+            # ---- zones (VLN-FF:694-756 / 777-812) -------------------------------------------------------
+            z_tok_slot, z_tok_inst, z_lens, z_mode, z_slot, z_row = [], [], [], [], [], []
+            m_env_a = np.asarray(m_env, np.int64)
+            for j_, e in enumerate(envs):
+                zrow, zmode, zoff, zmem = st.plan_zones(e, dirty_cells[m_env_a == j_] if len(m_env_a) else dirty_cells, int(n_seg[j_]))
+                for t in range(len(zrow)):
+                    mem = zmem[zoff[t]:zoff[t + 1]]
+                    z_tok_slot.append(np.full(len(mem), self.slots[e], np.int32)); z_tok_inst.append(mem)
+                    z_lens.append(len(mem)); z_mode.append(int(zmode[t])); z_slot.append(self.slots[e]); z_row.append(int(zrow[t]))
+            if max(st.count(e, st.ZROWS) for e in envs) > pools.z_cap:
+                raise RuntimeError("zone pool capacity exceeded (raise z_cap)")
+            if z_lens:
+                ts = self._i32(np.concatenate(z_tok_slot) if sum(z_lens) else np.zeros(0, np.int32))
+                ti = self._i32(np.concatenate(z_tok_inst) if sum(z_lens) else np.zeros(0, np.int32))
+                goff = self._i32(np.concatenate([[0], np.cumsum(z_lens)]))
+                gs, gr = self._i32(z_slot), self._i32(z_row)
+                geom4 = ops.group_stats4(pools, ts, ti, goff, self._i32(z_mode), gs, gr, len(z_lens), self.cell_len)
+                ifts = ops.gather_rows(pools.inst_fts, ts, ti) if sum(z_lens) else torch.zeros((0, FTS), device=self.device)
+                zfts = self.dense.encode_zone_sets(ifts, geom4, z_lens)
+                ops.scatter_rows(pools.zone_fts, gs, gr, zfts)
+            self._snapshot_tree()
+
+    # ---- a12 (VLN-FF:818-862) -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def get_environment_features(self, agent_position, agent_heading_angle, instance_distance=5.0, zone_distance=100.0):
+        B, st, pools = self.batch_size, self.state, self.pools
+        envs = list(range(B))
+        ids = [st.live_ids(e) for e in envs]
+        pose = self._poses(agent_position, agent_heading_angle, envs)
+        slot = self._i32([self.slots[e] for e in envs])
+        out = {}
+        for which, (pp, pf, radius, key) in enumerate(((pools.inst_pos, pools.inst_fts, instance_distance, "instance"),
+                                                       (pools.zone_pos, pools.zone_fts, zone_distance, "zone"))):
+            n_ids = np.array([len(i[which]) for i in ids], np.int32)
+            mx = max(1, int(n_ids.max()))
+            pad = np.zeros((B, mx), np.int32)
+            for e in envs:
+                pad[e, :n_ids[e]] = ids[e][which]
+            rel, fts, kept, count = self.ops.agent_frame_compact(pp, pf, slot, self._i32(pad), self._i32(n_ids), pose, float(radius))
+            out[key] = (rel, fts, kept, count)
+        ci, cz = out["instance"][3].cpu().numpy(), out["zone"][3].cpu().numpy()      # sync #4: Ni, Nz
+        return {
+            "batch_instance_fts": [out["instance"][1][e, :ci[e]] for e in envs],
+            "batch_instance_relative_position": [out["instance"][0][e, :ci[e]] for e in envs],
+            "batch_zone_fts": [out["zone"][1][e, :cz[e]] for e in envs],
+            "batch_zone_relative_position": [out["zone"][0][e, :cz[e]] for e in envs],
+            "batch_instance_ids": [out["instance"][2][e, :ci[e]] for e in envs],
+            "batch_zone_ids": [out["zone"][2][e, :cz[e]] for e in envs],
+        }
+
+    # ---- a13 (VLN-FF:296-326) -------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def get_patch_3d_info(self, batch_depth_map):
+        d = self._dev(batch_depth_map).view(-1, self.P)
+        outs = self.ops.patch_3d_info(d, self._camera())
+        return tuple(o.unsqueeze(-1) for o in outs)
+
+    # ---- test / debug export ------------------------------------------------------------------------------------------
+    def export_env(self, e: int):
+        st, pools, s = self.state, self.pools, self.slots[e]
+        ex = st.export(e)
+        nr, ns, nz = st.count(e, st.ROWS), st.count(e, st.SLOTS), st.count(e, st.ZROWS)
+        ex.update(rows_pos=pools.rows_pos[s, :nr].cpu().numpy(), ipos=pools.inst_pos[s, :ns].cpu().numpy(),
+                  ifts=pools.inst_fts[s, :ns].cpu().numpy(), zpos=pools.zone_pos[s, :nz].cpu().numpy(),
+                  zfts=pools.zone_fts[s, :nz].cpu().numpy())
+        L = np.array(self.cell_len, np.float32)
+        ex["zkey"] = {tuple((np.array(c, np.float32) * L + L / 2).tolist()): z for c, z in ex["zkey_cells"].items()}
+        return ex

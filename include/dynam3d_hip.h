@@ -1,0 +1,217 @@
+/* dynam3d_hip.h -- C ABI of libdynam3d_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the Dynam3D per-step 3D-token path.
+ * The reference is pure Python; its native operators are un-vendored pip packages.  Each entry
+ * point below names the reference call site (file:line under /root/reference) it replaces.
+ *   VLN-FF  = Dynam3D_VLN/vlnce_baselines/models/feature_fields.py
+ *   VLN-POL = Dynam3D_VLN/vlnce_baselines/models/Policy_Dynam3D_VLN.py
+ *   PRE-FF  = Dynam3D_Pretrain/src_3dff/models/feature_fields.py
+ *
+ * Conventions
+ *   - extern "C"; every function returns int32 (0 = ok, <0 = D3D_E*); d3d_last_error() returns a
+ *     thread-local message.
+ *   - all `*_d` / device buffers are caller-allocated DEVICE pointers (torch owns the memory; the
+ *     library neither frees nor retains them).  Host pointers are named `*_h`.
+ *   - sizes are int64/int32 as written; last argument is the hipStream_t (as void*) to launch on.
+ *   - launches are asynchronous; no implicit synchronisation.
+ *   - geometry kernels are compiled with -ffp-contract=off and are bit-exact against
+ *     oracle/geometry.py (one rounding per operation, fixed order).
+ */
+#ifndef DYNAM3D_HIP_H
+#define DYNAM3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3D_OK 0
+#define D3D_EINVAL (-1)
+#define D3D_EHIP (-2)
+#define D3D_ECAP (-3)
+#define D3D_ESTATE (-4)
+
+#define D3D_TOMBSTONE (-10000.0f) /* VLN-FF:357 */
+#define D3D_FTS_DIM 768
+
+const char* d3d_last_error(void);
+int32_t d3d_version(void);
+/* number of CUs / wave size seen by the library (sanity: 256 / 64 on MI355X) */
+int32_t d3d_device_info(int32_t* n_cu, int32_t* wave_size, int32_t* lds_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-view camera pose, prepared on the host exactly like the reference does in Python floats
+ * (math.cos/sin in double, then rounded to float32 at first use).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct d3d_pose {
+    float cam[3];   /* (x, -z, y) of the habitat position: VLN-FF:336, 523, 830 */
+    float cos_h;    /* (float)cos(heading)   -- unprojection  VLN-FF:290-291 */
+    float sin_h;
+    float cos_nh;   /* (float)cos(-heading)  -- frustum / agent frame  VLN-FF:95-99, 831-836 */
+    float sin_nh;
+    float heading;  /* (float)heading, added to the per-patch direction  VLN-FF:289 */
+} d3d_pose;
+
+/* a1  Dynam3D_VLN.preprocess_depth (VLN-POL:171-186): zero pixels <- column max, then metres.
+ * depth (B,H,W) f32 in [0,1] -> out (B,H,W) f32.  lo/hi = depth_scale. */
+int32_t d3d_preprocess_depth(const float* depth_d, float* out_d, int32_t B, int32_t H, int32_t W,
+                             float lo, float hi, void* stream);
+
+/* a2+a1 fused for the 24x24 copy: cv2.resize(INTER_NEAREST) (VLN-POL:339) then preprocess_depth
+ * on the resized image (VLN-POL:341).  src (B,H,W) -> out (B,h,w). */
+int32_t d3d_resize_nearest_preprocess(const float* depth_d, float* out_d, int32_t B, int32_t H, int32_t W,
+                                      int32_t h, int32_t w, float lo, float hi, void* stream);
+
+/* camera tables for a5/a13 are uploaded once per camera setting by the host wrapper:
+ * tan_xy[P], tan_z[P], dir0[P] (see oracle/geometry.py::camera_tables; VLN-FF:283-287). */
+
+/* a5  project_depth_to_3d_habitat + world offset (VLN-FF:276-293, 550-554).
+ * For env e (0..n_env-1): depth24_d[e*P .. ] metres, pose_d[e], writes P rows starting at
+ * row_base_d[e] of the env's slot slot_d[e] in the row pools (pool strides in rows = n_cap):
+ *   rows_pos (slots, n_cap, 3) f32, rows_dir / rows_scale (slots, n_cap) f32. */
+int32_t d3d_unproject_append(const float* depth24_d, const d3d_pose* pose_d, const int32_t* slot_d,
+                             const int32_t* row_base_d, int32_t n_env, int32_t P, int32_t W,
+                             const float* tan_xy_d, const float* tan_z_d, const float* dir0_d, float tan_half_hfov,
+                             float* rows_pos_d, float* rows_dir_d, float* rows_scale_d, int64_t n_cap, void* stream);
+
+/* append the CLIP grid features of the frame as float16 rows (VLN-FF:500, 567-570):
+ * grid (n_env, P, 768) f32|f16 -> rows_fts (slots, n_cap, 768) f16 at row_base. */
+int32_t d3d_append_fts(const void* grid_d, int32_t grid_is_f16, const int32_t* slot_d, const int32_t* row_base_d,
+                       int32_t n_env, int32_t P, uint16_t* rows_fts_d, int64_t n_cap, void* stream);
+
+/* a13 get_patch_3d_info (VLN-FF:296-326): depth24 (N,P) -> 5 x (N,P) f32. */
+int32_t d3d_patch_3d_info(const float* depth24_d, int32_t N, int32_t P, int32_t W, const float* tan_xy_d,
+                          const float* tan_z_d, const float* dir0_d, float tan_half_hfov, float* rel_x_d,
+                          float* rel_y_d, float* rel_z_d, float* dir_d, float* scale_d, void* stream);
+
+/* a4  get_frustum_mask_habitat + depth test + tomb-stoning (VLN-FF:88-115, 347-360).
+ * For env e: tests rows [0, n_rows_d[e]) of slot slot_d[e] against depth image e (Hd,Wd) metres.
+ * Hits are tomb-stoned in place (pos=-10000, fts/dir/scale=0) and their row indices are appended
+ * (unordered) to hits_d[e*hit_cap ..]; n_hits_d[e] must be zeroed by the caller. mask_d (optional,
+ * may be NULL) receives a byte mask (n_env, n_cap). */
+int32_t d3d_frustum_cull(float* rows_pos_d, uint16_t* rows_fts_d, float* rows_dir_d, float* rows_scale_d,
+                         int64_t n_cap, const int32_t* slot_d, const int32_t* n_rows_d, int32_t n_env,
+                         int32_t max_rows, const float* depth_d, int32_t Hd, int32_t Wd, const d3d_pose* pose_d,
+                         float fx, float fy, float cx, float cy, float near_, float far_, float slack,
+                         int32_t* hits_d, int32_t* n_hits_d, int32_t hit_cap, uint8_t* mask_d, void* stream);
+
+/* stand-alone mask (no mutation) for one point set -- used by tests and by torch-free callers. */
+int32_t d3d_frustum_mask(const float* points_d, int64_t n, const float* depth_d, int32_t Hd, int32_t Wd,
+                         const d3d_pose* pose_h, float fx, float fy, float cx, float cy, float near_, float far_,
+                         float slack, uint8_t* mask_d, void* stream);
+
+/* a8  torch_kdtree build_kd_tree / .query replacement (VLN-FF:246, 606-610; PRE-FF:364, 540, 584).
+ * Brute force, ascending (dist^2, index), ties -> lowest index; d2 = (dx*dx + dy*dy) + dz*dz.
+ * Batched: batch b uses points_d + b*point_stride (n_points_d[b] valid rows of 3 floats),
+ * queries_d + b*query_stride (n_queries_d[b] rows), k_d[b] <= k_max <= 8 neighbours;
+ * writes d2_d / idx_d at (b*max_queries + q)*k_max + j.  Strides are in floats. */
+int32_t d3d_knn(const float* points_d, int64_t point_stride, const int32_t* n_points_d, const float* queries_d,
+                int64_t query_stride, const int32_t* n_queries_d, const int32_t* k_d, int32_t n_batch,
+                int32_t max_queries, int32_t k_max, float* d2_d, int32_t* idx_d, void* stream);
+
+/* a7/a10 geometry: per-group centroid (float64 sequential mean, rounded once) + 7-vector
+ * [pos-centroid, |pos|, sin dir, cos dir, scale] for every member token (VLN-FF:582-591, 662-673).
+ * Groups are described CSR-style per token: tok_slot/tok_row (T) locate the member row, grp_off
+ * (G+1) delimits groups.  Outputs: centroid (G,3), cell (G,3) = floor(centroid/cell_len) as int32,
+ * geom (T,7).  If inst_pos_d != NULL and grp_inst_d[g] >= 0 the centroid is also stored to
+ * inst_pos[(grp_slot[g]*m_cap + grp_inst[g])*3] (merged-instance position update, VLN-FF:663). */
+int32_t d3d_group_stats7(const float* rows_pos_d, const float* rows_dir_d, const float* rows_scale_d, int64_t n_cap,
+                         const int32_t* tok_slot_d, const int32_t* tok_row_d, const int32_t* grp_off_d, int32_t G,
+                         int32_t T, float cell_x, float cell_y, float cell_z, float* centroid_d, int32_t* cell_d,
+                         float* geom_d, float* inst_pos_d, const int32_t* grp_slot_d, const int32_t* grp_inst_d,
+                         int64_t m_cap, void* stream);
+
+/* a11 geometry: zone centre + 4-vector [p - centre, |p|] (VLN-FF:714-723, 739-749).
+ * mode[g] = 0: members' true positions (new zone); 1: members' CELL CENTRES (updated zone, quirk).
+ * Writes centre to zone_pos[(slot*z_cap + zone_row[g])*3]; an empty group yields NaN (mean of empty). */
+int32_t d3d_group_stats4(const float* inst_pos_d, int64_t m_cap, const int32_t* tok_slot_d, const int32_t* tok_inst_d,
+                         const int32_t* grp_off_d, const int32_t* grp_mode_d, const int32_t* grp_slot_d,
+                         const int32_t* grp_zone_row_d, int32_t G, int32_t T, float cell_x, float cell_y, float cell_z,
+                         float* geom_d, float* zone_pos_d, int64_t z_cap, void* stream);
+
+/* gather float16 pool rows to float32 tokens: out[t,:] = f32(rows_fts[slot[t], row[t], :]). */
+int32_t d3d_gather_fts(const uint16_t* rows_fts_d, int64_t n_cap, const int32_t* tok_slot_d, const int32_t* tok_row_d,
+                       int32_t T, float* out_d, void* stream);
+
+/* generic float32 row gather / scatter over (slots, cap, D) pools: used for instance/zone features. */
+int32_t d3d_gather_rows_f32(const float* pool_d, int64_t cap, int32_t D, const int32_t* slot_d, const int32_t* row_d,
+                            int32_t T, float* out_d, void* stream);
+int32_t d3d_scatter_rows_f32(float* pool_d, int64_t cap, int32_t D, const int32_t* slot_d, const int32_t* row_d,
+                             int32_t T, const float* src_d, const int32_t* src_row_d, void* stream);
+/* rows <- constant (tomb-stoning of instances / zones: pos=-10000, fts=0; VLN-FF:378-379, 392-393) */
+int32_t d3d_fill_rows_f32(float* pool_d, int64_t cap, int32_t D, const int32_t* slot_d, const int32_t* row_d,
+                          int32_t T, float value, void* stream);
+
+/* a9 input: [ft_3d(768), ft_2d(768), new_pos - pos_3d] for every (query, proposal) (VLN-FF:613-617).
+ * pair_* (R) index the proposal instance (slot, inst) and the 2D instance (row of new_fts/new_pos). */
+int32_t d3d_merge_input(const float* inst_fts_d, const float* inst_pos_d, int64_t m_cap, const float* new_fts_d,
+                        const float* new_pos_d, const int32_t* pair_slot_d, const int32_t* pair_inst_d,
+                        const int32_t* pair_new_d, int32_t R, float* out_d, void* stream);
+
+/* a12 get_environment_features (VLN-FF:818-862): for env e, the ordered id list ids_d[e*max_ids ..]
+ * (n_ids_d[e] entries, dict order) is transformed into the agent frame and filtered by radius;
+ * survivors are compacted IN ORDER: rel (n_env,max_ids,3), fts (n_env,max_ids,768), count (n_env). */
+int32_t d3d_agent_frame_compact(const float* pool_pos_d, const float* pool_fts_d, int64_t cap, const int32_t* slot_d,
+                                const int32_t* ids_d, const int32_t* n_ids_d, int32_t n_env, int32_t max_ids,
+                                const d3d_pose* pose_d, float radius, float* rel_d, float* fts_d, int32_t* kept_ids_d,
+                                int32_t* count_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host-side bookkeeping (ids / dict semantics of VLN-FF:357-393, 433-475, 623-691, 694-756).
+ * Integer-only control plane; all float work stays in the kernels above.  Not thread-safe per
+ * handle.  compat: 0 = 'reference' (quirks F11/Z1 reproduced), 1 = 'fixed' (id == row).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct d3d_ff d3d_ff;
+
+d3d_ff* d3d_ff_create(int32_t compat_fixed, int32_t patches_per_view, int32_t num_proposals);
+void d3d_ff_destroy(d3d_ff* ff);
+int32_t d3d_ff_reset(d3d_ff* ff, int32_t batch_size);          /* VLN-FF:186-206 */
+int32_t d3d_ff_pop(d3d_ff* ff, int32_t env);                    /* VLN-FF:210-229 */
+int32_t d3d_ff_batch_size(const d3d_ff* ff);
+/* counters: which = 0 rows, 1 instance slots, 2 live instances, 3 zone rows, 4 live zones, 5 live patch ids */
+int64_t d3d_ff_count(const d3d_ff* ff, int32_t env, int32_t which);
+
+/* deletion cascade for one env (VLN-FF:362-393).  hits: row indices tomb-stoned by d3d_frustum_cull.
+ * inst cells must be current (see d3d_ff_set_inst_cells).  Outputs the instance slots and zone rows
+ * that must be tomb-stoned on the device. */
+int32_t d3d_ff_apply_hits(d3d_ff* ff, int32_t env, const int32_t* hits_h, int32_t n_hits, int32_t* dead_inst_h,
+                          int32_t* n_dead_inst, int32_t* dead_zone_h, int32_t* n_dead_zone, int32_t cap);
+
+/* start of a view update: appends P rows, returns row base and k0 = min(#live instances, K) */
+int32_t d3d_ff_begin_view(d3d_ff* ff, int32_t env, int32_t* row_base, int32_t* k0, int32_t* has_tree);
+
+/* merge planning (VLN-FF:604-691).  segm (P) dense labels, n_seg groups; d2/idx/logits laid out
+ * (n_seg, k_max[,2]) with k0 valid columns; new_cells (n_seg,3).  Outputs:
+ *   seg_slot (n_seg): instance slot that receives segment s' centroid/feature if NEW, else -1
+ *   dirty_inst (<= n_seg): merged instances needing centroid + re-encode, with CSR member rows
+ *   k_eff: proposals actually used after the tomb-stone shrink (VLN-FF:607-610) */
+int32_t d3d_ff_plan_merge(d3d_ff* ff, int32_t env, const int32_t* segm_h, int32_t n_seg, int32_t k0, int32_t k_max,
+                          const float* d2_h, const int32_t* idx_h, const float* logits_h, const int32_t* new_cells_h,
+                          int32_t* k_eff, int32_t* seg_slot_h, int32_t* dirty_inst_h, int32_t* n_dirty,
+                          int32_t* dirty_off_h, int32_t* dirty_rows_h, int32_t rows_cap);
+
+/* zone planning (VLN-FF:694-756).  dirty_cells (n_dirty,3) are the cells of the merged centroids.
+ * Outputs per touched zone: row to write, mode (0 new / 1 update), member instance CSR. */
+int32_t d3d_ff_plan_zones(d3d_ff* ff, int32_t env, const int32_t* dirty_cells_h, int32_t* n_touched,
+                          int32_t* zone_row_h, int32_t* zone_mode_h, int32_t* zone_off_h, int32_t* zone_members_h,
+                          int32_t zcap, int32_t mcap);
+
+/* end of view: snapshot for the next KNN (tree rebuild, VLN-FF:815); returns #slots in the tree */
+int32_t d3d_ff_end_view(d3d_ff* ff, int32_t env, int32_t* tree_slots);
+int32_t d3d_ff_rebuild_tree(d3d_ff* ff, int32_t env, int32_t* tree_slots);   /* VLN-FF:396 */
+
+/* dict-ordered live ids (VLN-FF:825, 844) */
+int32_t d3d_ff_live_ids(const d3d_ff* ff, int32_t env, int32_t* inst_ids_h, int32_t* n_inst, int32_t* zone_ids_h,
+                        int32_t* n_zone, int32_t cap);
+
+/* debug / test export of the dictionaries (sizes via d3d_ff_count; members as CSR in dict order) */
+int32_t d3d_ff_export_owner(const d3d_ff* ff, int32_t env, int32_t* owner_h, int64_t n);
+int32_t d3d_ff_export_members(const d3d_ff* ff, int32_t env, int32_t which /*0 inst,1 zone*/, int32_t* ids_h,
+                              int32_t* off_h, int32_t* flat_h, int64_t flat_cap);
+int32_t d3d_ff_export_zone_keys(const d3d_ff* ff, int32_t env, int32_t* cells_h /*(n,3)*/, int32_t* ids_h, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNAM3D_HIP_H */

@@ -1,0 +1,30 @@
+"""Shared trajectory-parity driver: runs dynam3d_amd.Feature_Fields (any ops backend/device) over a
+golden case and checks every step against the reference-generated fixture."""
+import numpy as np
+import torch
+
+from dynam3d_amd.feature_fields import Feature_Fields
+from dynam3d_amd.weights import ff_param_spec, synth_state_dict
+from tests.golden_io import TRAJ_CASES, load, traj_inputs
+from tests.test_oracle_golden import check_env_against_golden
+
+
+def run_case(name, ops, device, on_step=None):
+    case = TRAJ_CASES[name]
+    g = load(f"g4_{name}.npz")
+    sd = synth_state_dict(ff_param_spec(), seed=0)
+    ff = Feature_Fields(case["B"], device=device, state_dict=sd, ops=ops, max_steps=case["steps"] + 1)
+    ff.initialize_camera_setting(90.0, 90.0)
+    for t, inp in enumerate(traj_inputs(case)):
+        ff.delete_old_features_from_camera_frustum(torch.from_numpy(inp["depth_full"]), inp["positions"], inp["headings"])
+        ff.update_feature_fields(inp["depth24"], inp["grid"], None, inp["positions"], inp["headings"], patch_segm=inp["patch_segm"])
+        ev = ff.get_environment_features(inp["positions"], inp["headings"])
+        for b in range(case["B"]):
+            ex = ff.export_env(b)
+            env = dict(irel=ev["batch_instance_relative_position"][b].cpu().numpy(), zrel=ev["batch_zone_relative_position"][b].cpu().numpy(),
+                       ifts=ev["batch_instance_fts"][b].cpu().numpy(), zfts=ev["batch_zone_fts"][b].cpu().numpy())
+            check_env_against_golden(g, t, b, ex["owner"], ex["members"], ex["zmembers"], ex["zkey"], ex["ipos"], ex["ifts"],
+                                     ex["zpos"], ex["zfts"], ex["rows_pos"], env, t == case["steps"] - 1)
+        if on_step:
+            on_step(t, ff)
+    return ff
