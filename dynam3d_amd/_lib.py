@@ -35,7 +35,7 @@ SIGNATURES = {
 }
 
 # host bookkeeping half (bound in _ffstate.bind_ffstate); listed for the export test
-FFSTATE_SYMBOLS = ["d3d_ff_create", "d3d_ff_destroy", "d3d_ff_reset", "d3d_ff_pop", "d3d_ff_batch_size", "d3d_ff_count",
+FFSTATE_SYMBOLS = ["d3d_ff_create", "d3d_ff_destroy", "d3d_ff_set_tomb_cell", "d3d_ff_reset", "d3d_ff_pop", "d3d_ff_batch_size", "d3d_ff_count",
                    "d3d_ff_apply_hits", "d3d_ff_begin_view", "d3d_ff_plan_merge", "d3d_ff_plan_zones", "d3d_ff_end_view",
                    "d3d_ff_rebuild_tree", "d3d_ff_live_ids", "d3d_ff_export_owner", "d3d_ff_export_members",
                    "d3d_ff_export_zone_keys"]

@@ -167,6 +167,8 @@ typedef struct d3d_ff d3d_ff;
 d3d_ff* d3d_ff_create(int32_t compat_fixed, int32_t patches_per_view, int32_t num_proposals);
 void d3d_ff_destroy(d3d_ff* ff);
 int32_t d3d_ff_reset(d3d_ff* ff, int32_t batch_size);          /* VLN-FF:186-206 */
+/* cell index of a tomb-stoned instance position: floor(-10000 / cell_len) per axis */
+int32_t d3d_ff_set_tomb_cell(d3d_ff* ff, int32_t cx, int32_t cy, int32_t cz);
 int32_t d3d_ff_pop(d3d_ff* ff, int32_t env);                    /* VLN-FF:210-229 */
 int32_t d3d_ff_batch_size(const d3d_ff* ff);
 /* counters: which = 0 rows, 1 instance slots, 2 live instances, 3 zone rows, 4 live zones, 5 live patch ids */

@@ -1,0 +1,244 @@
+"""GPU (MI355X): the HIP kernels behind the C ABI against the golden vectors and the oracle.
+Integer / index / geometric outputs are compared BIT-EXACT; only sin/cos columns and dense features
+carry a tolerance (stated at the assert)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry as G
+from tests.golden_io import load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dynam3d_amd.ops import HipOps
+    o = HipOps()
+    n_cu, wave, lds = o.device_info()
+    assert wave == 64 and n_cu >= 64
+    return o
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def dev(a, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dt is None else t.to(dt)
+
+
+def test_unproject_and_patch_info_bit_exact(ops):
+    from dynam3d_amd.ops import CameraTables, Pools, make_pose
+    g = load("g1_unproject.npz")
+    n = int(g["n"])
+    cam = CameraTables.build(24, 24, 90.0, 90.0, "cuda")
+    pools = Pools.allocate(n, 2 * 576, 8, 8, "cuda")
+    depth = dev(np.stack([g[f"depth_{i}"] for i in range(n)]))
+    pose = dev(np.stack([make_pose(g[f"position_{i}"].tolist(), float(g[f"heading_{i}"])) for i in range(n)]))
+    slot = dev(np.arange(n, dtype=np.int32))
+    base = dev(np.full(n, 576, np.int32))
+    ops.unproject_append(depth, pose, slot, base, cam, pools)
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert np.array_equal(bits(pools.rows_pos[i, 576:].cpu().numpy()), bits(g[f"pos_{i}"]))
+        assert np.array_equal(bits(pools.rows_dir[i, 576:].cpu().numpy()), bits(g[f"dir_{i}"]))
+        assert np.array_equal(bits(pools.rows_scale[i, 576:].cpu().numpy()), bits(g[f"scale_{i}"]))
+        assert float(pools.rows_pos[i, :576].abs().sum()) == 0.0
+    outs = ops.patch_3d_info(dev(g["info_depth"]), cam)
+    for name, o in zip(["rel_x", "rel_y", "rel_z", "direction", "scale"], outs):
+        assert np.array_equal(bits(o.cpu().numpy()), bits(g["info_" + name][..., 0])), name
+
+
+def test_frustum_mask_bit_exact(ops):
+    from dynam3d_amd.ops import make_pose
+    g = load("g2_frustum.npz")
+    for i in range(int(g["n"])):
+        dimg = g[f"depth_{i}"]
+        Hd, Wd = dimg.shape
+        intr = (float(np.float32(Wd / np.tan(np.deg2rad(90.0) / 2.0) / 2.0)), float(np.float32(Hd / np.tan(np.deg2rad(90.0) / 2.0) / 2.0)), Wd / 2.0, Hd / 2.0)
+        m = ops.frustum_mask(dev(g[f"pts_{i}"]), dev(dimg), make_pose(g[f"position_{i}"].tolist(), float(g[f"heading_{i}"])), intr, 0.0, 3.0, 0.1)
+        assert np.array_equal(m.cpu().numpy().astype(bool), g[f"mask_{i}"])
+
+
+def test_frustum_cull_tombstones_and_hits(ops):
+    from dynam3d_amd.ops import Pools, make_pose
+    rng = np.random.default_rng(7)
+    B, N, cap = 3, 5000, 6000
+    pools = Pools.allocate(B, cap, 8, 8, "cuda")
+    pts = rng.uniform(-5, 5, (B, N, 3)).astype(np.float32)
+    pools.rows_pos[:, :N] = dev(pts)
+    pools.rows_fts[:, :N] = dev(rng.standard_normal((B, N, 768)).astype(np.float16))
+    pools.rows_dir[:, :N] = 1.0
+    pools.rows_scale[:, :N] = 2.0
+    n_rows = np.array([N, N - 1234, 17], np.int32)
+    depth = rng.uniform(0.5, 4.0, (B, 96, 96)).astype(np.float32)
+    poss = [[float(x) for x in rng.uniform(-1, 1, 3)] for _ in range(B)]
+    heads = [float(rng.uniform(0, 2 * math.pi)) for _ in range(B)]
+    intr = (48.0, 48.0, 48.0, 48.0)
+    hits = torch.full((B, N), -1, dtype=torch.int32, device="cuda")
+    n_hits = torch.zeros(B, dtype=torch.int32, device="cuda")
+    mask = torch.zeros((B, cap), dtype=torch.uint8, device="cuda")
+    ops.frustum_cull(pools, dev(np.arange(B, dtype=np.int32)), dev(n_rows), int(n_rows.max()), dev(depth),
+                     dev(np.stack([make_pose(p, h) for p, h in zip(poss, heads)])), intr, 0.0, 3.0, 0.1, hits, n_hits, mask)
+    torch.cuda.synchronize()
+    for b in range(B):
+        exp = G.frustum_mask_habitat(pts[b, :n_rows[b]], depth[b], poss[b], heads[b])
+        got = np.sort(hits[b, :int(n_hits[b])].cpu().numpy())
+        assert np.array_equal(got, np.nonzero(exp)[0])
+        assert np.array_equal(mask[b, :n_rows[b]].cpu().numpy().astype(bool), exp)
+        rp = pools.rows_pos[b, :N].cpu().numpy()
+        full = np.zeros(N, bool)
+        full[:n_rows[b]] = exp
+        assert np.all(rp[full] == -10000.0) and np.array_equal(bits(rp[~full]), bits(pts[b][~full]))
+        f = pools.rows_fts[b, :N].float().abs().sum(-1).cpu().numpy()
+        assert np.all(f[full] == 0) and np.all(f[~full] > 0)
+        assert np.all(pools.rows_dir[b, :N].cpu().numpy()[full] == 0) and np.all(pools.rows_scale[b, :N].cpu().numpy()[~full] == 2.0)
+
+
+def test_knn_golden_bit_exact(ops):
+    g = load("g3_knn.npz")
+    for i in range(int(g["n"])):
+        pts, q, k = g[f"pts_{i}"], g[f"q_{i}"], int(g[f"k_{i}"])
+        kmax = next(x for x in (1, 2, 4, 8) if x >= k)
+        d2, idx = ops.knn(dev(pts), 0, dev(np.array([len(pts)], np.int32)), dev(q), 0, dev(np.array([len(q)], np.int32)),
+                          dev(np.array([k], np.int32)), 1, len(q), kmax)
+        assert np.array_equal(idx[0, :, :k].cpu().numpy().astype(np.int64), g[f"idx_{i}"])
+        assert np.array_equal(bits(d2[0, :, :k].cpu().numpy()), bits(g[f"d2_{i}"]))
+
+
+def test_knn_large_batched_vs_oracle(ops):
+    """Pretrain-render regime (PRE-FF:540): thousands of queries against ~1e4 stored patches, k=4, batched."""
+    rng = np.random.default_rng(11)
+    nb, P, Q, k = 2, 9216, 3000, 4
+    pts = rng.uniform(-6, 6, (nb, P, 3)).astype(np.float32)
+    pts[:, ::97] = -10000.0
+    pts[:, 5] = pts[:, 1005]                                   # duplicates -> index tie-break
+    q = rng.uniform(-6, 6, (nb, Q, 3)).astype(np.float32)
+    q[:, 0] = pts[:, 5]
+    npts, nq = np.array([P, P - 1000], np.int32), np.array([Q, Q - 77], np.int32)
+    d2, idx = ops.knn(dev(pts), P * 3, dev(npts), dev(q), Q * 3, dev(nq), dev(np.array([k, 3], np.int32)), nb, Q, 4)
+    for b, kk in enumerate((4, 3)):
+        ed, ei = G.knn_bruteforce(pts[b, :npts[b]], q[b, :nq[b]], kk)
+        assert np.array_equal(idx[b, :nq[b], :kk].cpu().numpy().astype(np.int64), ei)
+        assert np.array_equal(bits(d2[b, :nq[b], :kk].cpu().numpy()), bits(ed))
+
+
+def test_depth_preprocess_and_resize_bit_exact(ops):
+    rng = np.random.default_rng(3)
+    for H, W in ((224, 224), (256, 256), (37, 53)):
+        d = rng.uniform(0.05, 0.5, (4, H, W, 1)).astype(np.float32)
+        d[rng.random(d.shape) < 0.02] = 0
+        d[0, :, 3] = 0                                            # an all-zero column
+        out = ops.preprocess_depth(dev(d)).cpu().numpy()
+        assert np.array_equal(bits(out), bits(G.preprocess_depth(d)))
+        small = ops.resize_nearest_preprocess(dev(d[..., 0]), 24, 24).cpu().numpy()
+        exp = G.preprocess_depth(G.downsample_depth_nearest(d))[..., 0]
+        assert np.array_equal(bits(small), bits(exp))
+
+
+def test_group_stats_vs_oracle(ops):
+    from dynam3d_amd.ops import Pools
+    rng = np.random.default_rng(5)
+    S, N = 2, 3000
+    pools = Pools.allocate(S, N, 64, 64, "cuda")
+    pos = rng.uniform(-8, 8, (S, N, 3)).astype(np.float32)
+    pos[:, ::50] = -10000.0
+    dr, sc = rng.uniform(0, 6.28, (S, N)).astype(np.float32), rng.uniform(0, 1, (S, N)).astype(np.float32)
+    pools.rows_pos.copy_(dev(pos)); pools.rows_dir.copy_(dev(dr)); pools.rows_scale.copy_(dev(sc))
+    lens = [1, 36, 0, 700, 2500, 5]
+    T = sum(lens)
+    ts = rng.integers(0, S, T).astype(np.int32)
+    tr = rng.integers(0, N, T).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    gslot = np.array([0, 1, 0, 1, 0, 1], np.int32)
+    ginst = np.array([3, -1, 5, 7, 9, 11], np.int32)
+    cen, cell, geom = ops.group_stats7(pools, dev(ts), dev(tr), dev(off), len(lens), (2.0, 2.0, 2.0), pools.inst_pos, dev(gslot), dev(ginst))
+    cen, cell, geom = cen.cpu().numpy(), cell.cpu().numpy(), geom.cpu().numpy()
+    for g_, n in enumerate(lens):
+        if n == 0:
+            assert np.all(np.isnan(cen[g_]))
+            continue
+        a, b = off[g_], off[g_ + 1]
+        p = pos[ts[a:b], tr[a:b]]
+        ec = G.mean_rows_f64(p)
+        assert np.array_equal(bits(cen[g_]), bits(ec))
+        assert np.array_equal(cell[g_], np.floor(ec / np.float32(2.0)).astype(np.int32))
+        eg = G.segment_geometry(p, dr[ts[a:b], tr[a:b]], sc[ts[a:b], tr[a:b]], ec)
+        assert np.array_equal(bits(geom[a:b, :4]), bits(eg[:, :4])) and np.array_equal(bits(geom[a:b, 6]), bits(eg[:, 6]))
+        assert np.allclose(geom[a:b, 4:6], eg[:, 4:6], atol=2e-7)          # float32 sin/cos: library ulp differences
+        if ginst[g_] >= 0:
+            assert np.array_equal(bits(pools.inst_pos[gslot[g_], ginst[g_]].cpu().numpy()), bits(ec))
+    # zones (4-vector), modes 0/1 and an empty group
+    ip = rng.uniform(-9, 9, (S, 64, 3)).astype(np.float32)
+    pools.inst_pos.copy_(dev(ip))
+    zl = [3, 0, 7, 1]
+    zt = sum(zl)
+    zs, zi = rng.integers(0, S, zt).astype(np.int32), rng.integers(0, 64, zt).astype(np.int32)
+    zoff = np.concatenate([[0], np.cumsum(zl)]).astype(np.int32)
+    mode, gs, gr = np.array([0, 0, 1, 1], np.int32), np.array([0, 1, 1, 0], np.int32), np.array([5, 6, 7, 8], np.int32)
+    g4 = ops.group_stats4(pools, dev(zs), dev(zi), dev(zoff), dev(mode), dev(gs), dev(gr), 4, (2.0, 2.0, 2.0)).cpu().numpy()
+    for g_, n in enumerate(zl):
+        zp = pools.zone_pos[gs[g_], gr[g_]].cpu().numpy()
+        if n == 0:
+            assert np.all(np.isnan(zp))
+            continue
+        a, b = zoff[g_], zoff[g_ + 1]
+        p = ip[zs[a:b], zi[a:b]]
+        if mode[g_] == 1:
+            p = G.zone_cell_centre(p)
+        ec = G.mean_rows_f64(p)
+        assert np.array_equal(bits(zp), bits(ec))
+        assert np.array_equal(bits(g4[a:b, :3]), bits((p - ec[None]).astype(np.float32)))
+
+
+def test_row_movers_and_agent_frame(ops):
+    from dynam3d_amd.ops import Pools, make_pose
+    rng = np.random.default_rng(9)
+    S = 3
+    pools = Pools.allocate(S, 64, 300, 16, "cuda")
+    ip = rng.uniform(-7, 7, (S, 300, 3)).astype(np.float32)
+    ip[:, ::9] = -10000.0
+    ift = rng.standard_normal((S, 300, 768)).astype(np.float32)
+    pools.inst_pos.copy_(dev(ip)); pools.inst_fts.copy_(dev(ift))
+    n_ids = np.array([300, 0, 123], np.int32)
+    ids = np.stack([rng.permutation(300) for _ in range(S)]).astype(np.int32)
+    poss = [[float(x) for x in rng.uniform(-2, 2, 3)] for _ in range(S)]
+    heads = [float(rng.uniform(0, 6.28)) for _ in range(S)]
+    rel, fts, kept, cnt = ops.agent_frame_compact(pools.inst_pos, pools.inst_fts, dev(np.array([2, 0, 1], np.int32)), dev(ids), dev(n_ids),
+                                                  dev(np.stack([make_pose(p, h) for p, h in zip(poss, heads)])), 5.0)
+    for e, s in enumerate([2, 0, 1]):
+        idl = ids[e, :n_ids[e]]
+        er, ek = G.agent_frame(ip[s][idl], poss[e], heads[e], 5.0)
+        c = int(cnt[e])
+        assert c == int(ek.sum())
+        assert np.array_equal(kept[e, :c].cpu().numpy(), idl[ek])
+        assert np.array_equal(bits(rel[e, :c].cpu().numpy()), bits(er[ek]))
+        assert np.array_equal(bits(fts[e, :c].cpu().numpy()), bits(ift[s][idl[ek]]))
+    # gather / scatter / fill / fts gather / merge input
+    sl, rw = dev(np.array([0, 2, 1, 1], np.int32)), dev(np.array([5, 299, 0, 17], np.int32))
+    got = ops.gather_rows(pools.inst_fts, sl, rw).cpu().numpy()
+    assert np.array_equal(bits(got), bits(ift[[0, 2, 1, 1], [5, 299, 0, 17]]))
+    src = dev(rng.standard_normal((6, 768)).astype(np.float32))
+    ops.scatter_rows(pools.inst_fts, sl, rw, src, dev(np.array([5, 4, 0, 1], np.int32)))
+    assert torch.equal(pools.inst_fts[2, 299], src[4]) and torch.equal(pools.inst_fts[1, 17], src[1])
+    ops.fill_rows(pools.inst_pos, sl, rw, -10000.0)
+    assert float(pools.inst_pos[1, 0].sum()) == -30000.0
+    h16 = rng.standard_normal((S, 64, 768)).astype(np.float16)
+    pools.rows_fts.copy_(dev(h16))
+    gf = ops.gather_fts(pools, dev(np.array([1, 2], np.int32)), dev(np.array([63, 0], np.int32))).cpu().numpy()
+    assert np.array_equal(gf, h16[[1, 2], [63, 0]].astype(np.float32))
+    nf, npos = dev(rng.standard_normal((4, 768)).astype(np.float32)), dev(rng.uniform(-3, 3, (4, 3)).astype(np.float32))
+    x = ops.merge_input(pools, nf, npos, dev(np.array([0, 2], np.int32)), dev(np.array([7, 8], np.int32)), dev(np.array([3, 1], np.int32)))
+    exp = torch.cat([pools.inst_fts[[0, 2], [7, 8]], nf[[3, 1]], npos[[3, 1]] - pools.inst_pos[[0, 2], [7, 8]]], -1)
+    assert torch.equal(x, exp)
+    # append_fts: f32 -> f16 rounding and f16 passthrough
+    grid = dev(rng.standard_normal((2, 576, 768)).astype(np.float32) * 3)
+    pools2 = Pools.allocate(2, 1200, 4, 4, "cuda")
+    ops.append_fts(grid, dev(np.array([1, 0], np.int32)), dev(np.array([10, 600], np.int32)), pools2)
+    assert torch.equal(pools2.rows_fts[1, 10:586], grid[0].half()) and torch.equal(pools2.rows_fts[0, 600:1176], grid[1].half())
+    ops.append_fts(grid.half(), dev(np.array([0, 1], np.int32)), dev(np.array([0, 600], np.int32)), pools2)
+    assert torch.equal(pools2.rows_fts[0, 0:576], grid[0].half())
