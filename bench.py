@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""Headline benchmark: nav steps/s, RGB-D observation -> action logits, batch 8 per GPU (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the whole hot path (depth prep, CLIP ViT-L/14@336, frustum
+delete, 3D-token update, agent-frame query, prefix MLPs, llava vision tower, Phi-3-mini prefill to the logits
+of the first generated token) over a batch of 8 synthetic 224x224 posed RGB-D observations already resident
+in HBM.  The memory is first advanced 8 untimed steps (the "warm" operating point of SURVEY.md 8d).
+Prints ONE JSON line (rank 0)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16 MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def step_flops(cfg, lengths, n_img):
+    """Algorithmic FLOPs of one batch step (BASELINE.md section 3 formula, evaluated exactly for the configs and
+    the real (unpadded, causal) sequence lengths)."""
+    v, l = cfg.vit, cfg.llm
+    L, W = v.tokens, v.width
+    layer = 2 * L * W * (3 * W + W + 2 * v.mlp) + 4 * L * L * W
+    embed = 2 * (L - 1) * 3 * v.patch * v.patch * W
+    clip = v.layers * layer + embed + 2 * L * W * v.out_dim
+    llava = (v.layers - 1) * layer + embed + 2 * (L - 1) * (W * v.proj_dim + v.proj_dim * v.proj_dim)
+    per_tok = 2 * (l.hidden * (l.heads + 2 * l.kv_heads) * l.head_dim + l.heads * l.head_dim * l.hidden + 3 * l.hidden * l.mlp)
+    phi = sum(l.layers * (per_tok * S + 2 * S * S * l.heads * l.head_dim) + 2 * l.hidden * l.vocab for S in lengths)
+    tok3d = n_img * 17e9        # SURVEY 8a row a7 (2-layer set encoder over 576+n tokens), informational
+    return dict(clip=n_img * clip, llava=n_img * llava, phi3=phi, tokens3d=tok3d, total=n_img * (clip + llava) + phi + tok3d)
+
+
+def cpu_baseline(cfg, seed, n_threads):
+    """Whole-step oracle ("port") on the host cores, bounded sample: ONE environment, one cold step."""
+    from dynam3d_amd.policy import SyntheticTokenizer, synth_policy_weights
+    from dynam3d_amd.synthetic import INSTRUCTION_64, SyntheticEpisodes
+    from oracle.step_oracle import StepOracle
+    torch.set_num_threads(n_threads)
+    sd = synth_policy_weights(cfg, seed)
+    orc = StepOracle(sd, cfg.vit, cfg.llm, 1, SyntheticTokenizer(cfg.llm.vocab))
+    fr = SyntheticEpisodes(1, seed=seed).next()
+    t0 = time.time()
+    orc.forward_logits(fr.rgb, fr.depth, [INSTRUCTION_64], [fr.positions[0].tolist()], list(fr.headings), fr.patch_segm)
+    dt = time.time() - t0
+    return dict(value=1.0 / dt, unit="env-steps/s", cores=n_threads, kind="port",
+                sample="1 environment x 1 cold step of the same full-size model (float32 oracle/step_oracle.py), S=%d" % orc.last_lengths[0],
+                seconds=round(dt, 2), stages={k: round(v, 3) for k, v in orc.timing.items()})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--warm-steps", type=int, default=8, help="untimed trajectory steps before warmup (warm memory)")
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "on", "off"])
+    ap.add_argument("--hip-dense", default="all", help="comma list of dense primitives to run on hand-written HIP kernels, 'all' or 'none'")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+
+    from dynam3d_amd import dense_ops as D
+    from dynam3d_amd import dist as DD
+    from dynam3d_amd.policy import Dynam3D_VLN, PolicyConfig, synth_policy_weights
+    from dynam3d_amd.profiling import TIMER
+    from dynam3d_amd.synthetic import INSTRUCTION_64, SyntheticEpisodes
+
+    rank, local, world = DD.init_from_env()
+    assert world == a.gpus or world == 1, (world, a.gpus)
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    cfg = PolicyConfig()
+    if a.hip_dense != "none":
+        try:
+            D.enable_hip_kernels(a.hip_dense.split(","))
+        except ImportError:
+            pass
+    B = a.batch
+    sd = synth_policy_weights(cfg, a.seed, device=dev)
+    net = Dynam3D_VLN(cfg, sd, device=dev, batch_size=B, max_steps=a.warm_steps + a.warmup + a.steps + 2)
+    del sd
+    net.feature_fields.initialize_camera_setting(90.0, 90.0)
+    ep = SyntheticEpisodes(B, seed=a.seed + 1000 * rank)       # independent episodes per rank (VLN-TR:141)
+    instr = [INSTRUCTION_64] * B
+    total = a.warm_steps + a.warmup + a.steps
+    frames = []
+    for _ in range(total):                                      # inputs resident in HBM before the timed region
+        fr = ep.next()
+        frames.append((dict(rgb=torch.from_numpy(fr.rgb).to(dev), depth=torch.from_numpy(fr.depth).to(dev)),
+                       [p.tolist() for p in fr.positions], list(fr.headings), fr.patch_segm))
+
+    def run(i):
+        obs, pos, hd, segm = frames[i]
+        return net.forward_logits(obs, instr, pos, hd, patch_segm=segm)
+
+    for i in range(a.warm_steps + a.warmup):
+        run(i)
+    torch.cuda.synchronize()
+    DD.barrier()
+    TIMER.enabled = True
+    lengths_seen = []
+    t0 = time.perf_counter()
+    for i in range(a.warm_steps + a.warmup, total):
+        lo = run(i)
+        lengths_seen.append(list(net.last_lengths))
+    torch.cuda.synchronize()
+    DD.barrier()
+    dt = DD.max_over_ranks(time.perf_counter() - t0, device=dev)
+    TIMER.enabled = False
+    assert torch.isfinite(lo).all()
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        fl = step_flops(cfg, lengths_seen[-1], B)
+        S_pad = max(lengths_seen[-1])
+        tsum = TIMER.summary()
+        n_gu, ms_gu = tsum.get("phi3.gate_up_proj", (0, float("nan")))
+        l = cfg.llm
+        gu_flops = 2.0 * B * S_pad * l.hidden * 2 * l.mlp
+        achieved = gu_flops / (ms_gu * 1e-3) / 1e12 if n_gu else float("nan")
+        st = net.feature_fields.state
+        out = {
+            "metric": "nav steps/sec (RGB-D obs->action logits) at batch=8", "value": round(B * a.steps * a.gpus / dt, 3), "unit": "env-steps/s",
+            "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[2]: full Dynam3D-VLN step (3D tokens + llava-phi-3-mini prefill -> action logits), batch=8 synthetic 224x224 RGB-D, 1 MI355X per rank",
+                       "batch_per_gpu": B, "operating_point": f"warm (memory advanced {a.warm_steps} steps)", "S_tokens": lengths_seen[-1],
+                       "Ni": net.last_counts["Ni"], "Nz": net.last_counts["Nz"], "rows_per_env": st.count(0, st.ROWS),
+                       "instances_per_env": st.count(0, st.LIVE), "clip_dtype": str(cfg.clip_dtype), "llm_dtype": str(cfg.llava_dtype),
+                       "token_builder_dtype": "float32", "parallelism": f"episode-parallel x{a.gpus} (no data-path collective)",
+                       "dense_backend": dict(D.BACKEND)},
+            "roofline": {"bound": "mfma", "kernel": "phi3.gate_up_proj GEMM (B*S x 3072 x 16384, bf16)", "achieved": round(achieved, 1),
+                         "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
+                         "launches_timed": n_gu, "avg_launch_ms": round(ms_gu, 4),
+                         "step_total_tflop": round(fl["total"] / 1e12, 2), "step_frac_of_peak": round(fl["total"] / (ms * 1e-3) / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4),
+                         "step_flop_split_tflop": {k: round(v / 1e12, 3) for k, v in fl.items() if k != "total"}},
+        }
+        do_cpu = a.cpu_baseline == "on" or (a.cpu_baseline == "auto" and a.gpus == 1)
+        if do_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, a.seed, os.cpu_count() or 1)
+            except Exception as e:  # never lose the GPU line because the host baseline failed
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    DD.barrier()
+
+
+if __name__ == "__main__":
+    main()

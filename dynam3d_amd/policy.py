@@ -1,0 +1,279 @@
+"""`Dynam3D_VLN` -- drop-in for the reference policy net's per-step call
+(Dynam3D_VLN/vlnce_baselines/models/Policy_Dynam3D_VLN.py:66-506, "VLN-POL"):
+
+    net(observations, instructions, agent_positions, agent_heading_angles, depth_scale=(0.,10.),
+        gt_text=None, delete_old_features=True, num_of_views=1, is_train=False)          (VLN-POL:329, VLN-TR:671)
+
+plus `net.feature_fields.*`, `net.convert_text_to_action(texts)` and -- for the benchmark metric --
+`net.forward_logits(...) -> (B, vocab)`: the LM logits at the last prompt position of the very same
+`inputs_embeds` the reference hands to `llava.generate`.
+
+MI355X-first differences from the reference's data flow (results unchanged):
+  * nothing leaves the GPU between the camera frame and the logits: CLIP grid features stay on the
+    device as fp16 (the reference round-trips them through numpy, VLN-POL:345), depth is resized and
+    pre-processed by one HIP kernel instead of a per-image cv2 loop (VLN-POL:336-341);
+  * one image pre-processing feeds both ViT towers;
+  * the batch is right-padded with per-row offsets and per-row action history.
+"""
+from __future__ import annotations
+
+import math
+import re
+import zlib
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import dense_ops as D
+from .feature_fields import Feature_Fields
+from .towers import (ClipVisionTower, LlavaVisionTower, Phi3Config, Phi3Decoder, VitConfig, clip_param_spec,
+                     llava_vision_param_spec, phi3_param_spec, preprocess_rgb)
+from .weights import ff_param_spec, synth_state_dict
+
+
+def prefix_param_spec(width: int = 768, hidden: int = None):
+    """VLN-POL:83-111 (hidden = width*4 = the LM width in the reference; separately settable for small test configs)."""
+    hidden = hidden or 4 * width
+    s = []
+
+    def seq(name, din, dh, dout):
+        s.extend([(f"{name}.0.weight", (dh, din)), (f"{name}.0.bias", (dh,)), (f"{name}.1.weight", (dh,)), (f"{name}.1.bias", (dh,)),
+                  (f"{name}.3.weight", (dout, dh)), (f"{name}.3.bias", (dout,))])
+
+    seq("patch_position_embedding", 6, hidden, hidden)
+    seq("instance_position_embedding", 3, width, width)
+    seq("zone_position_embedding", 3, width, width)
+    seq("instance_projector", 2 * width, hidden, hidden)
+    seq("zone_projector", 2 * width, hidden, hidden)
+    return s
+
+
+class SyntheticTokenizer:
+    """Deterministic stand-in for the llava-phi-3-mini tokenizer (its files are not available offline:
+    "parity unpinned" at this boundary).  Special tokens take the Phi-3 / llava ids; every other
+    whitespace-delimited piece is hashed into the ordinary vocabulary range."""
+    BOS, NEWLINE = 1, 13
+    SPECIAL = {"<|user|>": 32010, "<|end|>": 32007, "<|assistant|>": 32001, "<image>": 32038, "<|endoftext|>": 32000}
+
+    def __init__(self, vocab: int = 32064):
+        self.vocab = vocab
+        self._re = re.compile(r"(<\|[a-z]+\|>|<image>|\n|[^\s<]+|<)")
+
+    def encode(self, text: str, bos: bool = False) -> List[int]:
+        out = [self.BOS] if bos else []
+        hi = min(32000, self.vocab) - 100
+        for piece in self._re.findall(text):
+            if piece in self.SPECIAL:
+                out.append(self.SPECIAL[piece] % self.vocab)
+            elif piece == "\n":
+                out.append(self.NEWLINE)
+            else:
+                out.append(100 + zlib.crc32(piece.encode()) % hi)
+        return out
+
+    def decode(self, ids: Sequence[int]) -> str:
+        inv = {v % self.vocab: k for k, v in self.SPECIAL.items()}
+        return " ".join(inv.get(int(i), "\n" if int(i) == self.NEWLINE else f"<{int(i)}>") for i in ids)
+
+
+@dataclass
+class PolicyConfig:
+    vit: VitConfig = field(default_factory=VitConfig)
+    llm: Phi3Config = field(default_factory=Phi3Config)
+    clip_dtype: torch.dtype = torch.float16      # reference: clip.load(..., device=cuda) -> fp16 (resnet_encoders.py:260)
+    llava_dtype: torch.dtype = torch.bfloat16    # reference: torch_dtype=torch.bfloat16 (VLN-POL:125)
+    depth_quirk: bool = False                    # True reproduces `observations['depth'][b][i]` row indexing
+    compat: str = "reference"
+
+
+def synth_policy_weights(cfg: PolicyConfig, seed: int = 0, device: str = "cpu") -> Dict[str, torch.Tensor]:
+    spec = (ff_param_spec(768) + prefix_param_spec(768, cfg.llm.hidden) + clip_param_spec(cfg.vit) + llava_vision_param_spec(cfg.vit)
+            + phi3_param_spec(cfg.llm))
+    dtype_for = None
+    if device != "cpu":      # benchmark-sized model generated on the GPU: store tower weights directly in their compute dtype
+        def dtype_for(name):
+            if name.startswith("visual."):
+                return cfg.clip_dtype if not name.split(".")[-2].startswith("ln_") else torch.float32
+            if name.startswith(("vision_tower.", "multi_modal_projector.", "language_model.")):
+                return cfg.llava_dtype if "norm" not in name else torch.float32
+            return torch.float32
+    return synth_state_dict(spec, seed, device=device, dtype_for=dtype_for)
+
+
+class Dynam3D_VLN:
+    def __init__(self, cfg: PolicyConfig = PolicyConfig(), weights: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0,
+                 device="cuda", batch_size: int = 1, ops=None, tokenizer=None, segmenter=None, max_steps: int = 64):
+        self.cfg, self.device = cfg, torch.device(device)
+        sd = weights if weights is not None else synth_policy_weights(cfg, seed)
+        ff_sd = {k: sd[k] for k, _ in ff_param_spec(768)}
+        self.feature_fields = Feature_Fields(batch_size, device, ff_sd, compat=cfg.compat, ops=ops, segmenter=segmenter, max_steps=max_steps)
+        self.ops = self.feature_fields.ops
+        self.rgb_encoder = ClipVisionTower(sd, cfg.vit, cfg.clip_dtype, device)
+        self.llava_vision = LlavaVisionTower(sd, cfg.vit, cfg.llava_dtype, device)
+        self.llm = Phi3Decoder(sd, cfg.llm, cfg.llava_dtype, device)
+        self.mlp_w = {k: sd[k].to(self.device, torch.float32).contiguous() for k, _ in prefix_param_spec(768, cfg.llm.hidden)}
+        self.tokenizer = tokenizer or SyntheticTokenizer(cfg.llm.vocab)
+        self.last_lengths = None
+
+    # ---- reference surface -----------------------------------------------------------------------------
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def preprocess_depth(self, depth, depth_scale=(0.0, 10.0)):
+        """VLN-POL:171-186; depth (B,H,W,1) -> same shape, metres."""
+        d = depth.to(self.device)
+        return self.ops.preprocess_depth(d.reshape(d.shape[0], d.shape[1], d.shape[2]), depth_scale[0], depth_scale[1]).view(d.shape)
+
+    def _mlp(self, x, name):
+        import torch.nn.functional as F
+        w = self.mlp_w
+        h = F.linear(x, w[name + ".0.weight"], w[name + ".0.bias"])
+        h = F.layer_norm(h, (h.shape[-1],), w[name + ".1.weight"], w[name + ".1.bias"], 1e-5)
+        return F.linear(F.gelu(h), w[name + ".3.weight"], w[name + ".3.bias"])
+
+    def _depth24(self, depth, V, depth_scale):
+        B = depth.shape[0]
+        a = self.feature_fields.args
+        if not self.cfg.depth_quirk:
+            return self.ops.resize_nearest_preprocess(depth[..., 0], a.input_height, a.input_width, *depth_scale).view(B // V, V, -1)
+        # quirk F9: depth[b][i] is image ROW i (shape (W,1)); cv2 resizes that column vector to 24x24
+        Wd = depth.shape[2]
+        ri = torch.from_numpy(np.minimum(np.floor(np.arange(a.input_height) * (Wd / a.input_height)).astype(np.int64), Wd - 1)).to(depth.device)
+        rows = torch.stack([depth[b // V, b % V, :, 0][ri] for b in range(B)])            # (B,24)
+        img = rows[:, :, None].expand(B, a.input_height, a.input_width).contiguous()
+        return self.ops.resize_nearest_preprocess(img, a.input_height, a.input_width, *depth_scale).view(B // V, V, -1)
+
+    @torch.no_grad()
+    def build_inputs(self, observations, instructions, agent_positions, agent_heading_angles, depth_scale=(0.0, 10.0),
+                     delete_old_features=True, num_of_views=1, patch_segm=None):
+        """Everything up to the LM: returns (inputs_embeds (B,S,3072) right-padded, lengths (B,))  (VLN-POL:331-461)."""
+        ff, V = self.feature_fields, num_of_views
+        B = ff.batch_size
+        rgb = observations["rgb"].to(self.device)
+        depth = observations["depth"].to(self.device, torch.float32)
+        depth24 = self._depth24(depth, V, depth_scale)                                        # (B,V,576) metres
+        pixels = preprocess_rgb(rgb)                                                          # shared by both towers
+        _, grid = self.rgb_encoder.forward(pixels)                                            # (B*V,576,768) fp16, stays on device
+        if delete_old_features:
+            dfull = self.ops.preprocess_depth(depth[..., 0], *depth_scale).view(B, V, depth.shape[1], depth.shape[2])
+            ff.delete_old_features_from_camera_frustum(dfull, agent_positions, agent_heading_angles, num_of_views=V)
+        ff.update_feature_fields(depth24, grid.view(B, V, ff.P, -1), rgb, agent_positions, agent_heading_angles, num_of_views=V,
+                                 patch_segm=patch_segm)
+        env = ff.get_environment_features(agent_positions, agent_heading_angles)
+        rel_x, rel_y, rel_z, direction, scale = ff.get_patch_3d_info(depth24.reshape(B * V, -1))
+        info = torch.cat([rel_x, rel_y, rel_z, torch.sin(direction), torch.cos(direction), scale], dim=-1)   # VLN-POL:432
+        patch_pos = self._mlp(info, "patch_position_embedding")                               # (B*V,576,3072)
+        ni = [int(t.shape[0]) for t in env["batch_instance_fts"]]
+        nz = [int(t.shape[0]) for t in env["batch_zone_fts"]]
+        ifts, irel = torch.cat(env["batch_instance_fts"]), torch.cat(env["batch_instance_relative_position"])
+        zfts, zrel = torch.cat(env["batch_zone_fts"]), torch.cat(env["batch_zone_relative_position"])
+        inst_tok = self._mlp(torch.cat([ifts, self._mlp(irel, "instance_position_embedding")], -1), "instance_projector")   # VLN-POL:434
+        zone_tok = self._mlp(torch.cat([zfts, self._mlp(zrel, "zone_position_embedding")], -1), "zone_projector")           # VLN-POL:435
+        patch_tok = self.llava_vision.forward(pixels).float() + patch_pos                      # VLN-POL:448-453
+        patch_tok = patch_tok.view(B, V * ff.P, -1)
+        # prompt (VLN-POL:436): ids 0..1 are kept in front of the visual prefix, the text follows it
+        tok = self.tokenizer
+        head = torch.tensor(tok.encode("<|user|>", bos=True), device=self.device)
+        head_e = self.llm.embed_tokens(head).float()
+        rows, lengths = [], []
+        io, zo = np.concatenate([[0], np.cumsum(ni)]), np.concatenate([[0], np.cumsum(nz)])
+        for b in range(B):
+            text = ("\nInstruction:\n" + instructions[b] + "\nHistory actions:\n" + "".join(ff.history_actions[b])
+                    + "<|end|>\n<|assistant|>\nNext action:\n")
+            te = self.llm.embed_tokens(torch.tensor(tok.encode(text), device=self.device)).float()
+            row = torch.cat([head_e, patch_tok[b], inst_tok[io[b]:io[b + 1]], zone_tok[zo[b]:zo[b + 1]], te], 0)   # VLN-POL:456
+            rows.append(row)
+            lengths.append(row.shape[0])
+        S = max(lengths)
+        embeds = torch.zeros((B, S, self.cfg.llm.hidden), dtype=self.cfg.llava_dtype, device=self.device)
+        for b, r in enumerate(rows):
+            embeds[b, :r.shape[0]] = r.to(self.cfg.llava_dtype)
+        self.last_lengths = lengths
+        self.last_counts = dict(Ni=ni, Nz=nz)
+        return embeds, torch.tensor(lengths, device=self.device)
+
+    @torch.no_grad()
+    def forward_logits(self, observations, instructions, agent_positions, agent_heading_angles, depth_scale=(0.0, 10.0),
+                       gt_text=None, delete_old_features=True, num_of_views=1, is_train=False, patch_segm=None) -> torch.Tensor:
+        embeds, lengths = self.build_inputs(observations, instructions, agent_positions, agent_heading_angles, depth_scale,
+                                            delete_old_features, num_of_views, patch_segm)
+        return self.llm.prefill_logits(embeds, lengths)
+
+    @torch.no_grad()
+    def forward(self, observations, instructions, agent_positions, agent_heading_angles, depth_scale=(0.0, 10.0), gt_text=None,
+                delete_old_features=True, num_of_views=1, is_train=False, patch_segm=None, max_new_tokens: int = 20):
+        """Eval branch of VLN-POL:430-469: greedy text generation + per-row history update.  The decode loop
+        recomputes the prefix each token (no KV cache yet -- SURVEY.md 8f-4); the benchmarked metric is
+        `forward_logits`."""
+        if is_train:
+            raise NotImplementedError("training branch (loss over gt_text) is outside the hot path: SURVEY.md 8f-1")
+        embeds, lengths = self.build_inputs(observations, instructions, agent_positions, agent_heading_angles, depth_scale,
+                                            delete_old_features, num_of_views, patch_segm)
+        B = embeds.shape[0]
+        gen = [[] for _ in range(B)]
+        done = [False] * B
+        end_id = self.tokenizer.SPECIAL["<|end|>"] % self.cfg.llm.vocab
+        for _ in range(max_new_tokens):
+            nxt = self.llm.prefill_logits(embeds, lengths).argmax(-1)
+            S = int(lengths.max()) + 1
+            if S > embeds.shape[1]:
+                embeds = torch.cat([embeds, torch.zeros((B, S - embeds.shape[1], embeds.shape[2]), dtype=embeds.dtype, device=self.device)], 1)
+            e = self.llm.embed_tokens(nxt)
+            for b in range(B):
+                if done[b]:
+                    continue
+                gen[b].append(int(nxt[b]))
+                done[b] = int(nxt[b]) == end_id
+                embeds[b, int(lengths[b])] = e[b]
+            lengths = lengths + torch.tensor([0 if d and len(g) and g[-1] != end_id else 1 for d, g in zip(done, gen)], device=self.device)
+            if all(done):
+                break
+        texts = []
+        for b in range(B):
+            t = self.tokenizer.decode(gen[b])
+            cut = t.find("<|end|>")
+            t = t[:cut] if cut >= 0 else t
+            texts.append(t)
+            self.feature_fields.history_actions[b].pop(0)                                       # VLN-POL:466-468
+            self.feature_fields.history_actions[b].append(t + "\n")
+        return texts
+
+    # ---- a18 (VLN-POL:472-506) ----------------------------------------------------------------------------------
+    @staticmethod
+    def convert_text_to_action(generated_text: Sequence[str]):
+        """'turn left/right k steps, move m steps.' -> (angle rad, distance m); stop / error / malformed -> -100.
+        Where the reference raises (unparsable integers, 'move' without a turn: NameError/ValueError) this
+        returns -100."""
+        angle_per_step, distance_per_step, max_turn_steps = 15, 0.25, 4
+        out = []
+        for text in generated_text:
+            try:
+                if "stop" in text or "error" in text:
+                    out.append(-100)
+                    continue
+                angle, distance = 0.0, 0.0
+                side = "left" if "left" in text else ("right" if "right" in text else None)
+                if side is None:
+                    if "move" in text:
+                        out.append(-100)       # reference: unbound `start`/`end` -> NameError
+                        continue
+                    out.append((angle, distance))
+                    continue
+                start = text.find(side) + len(side)
+                end = text.find("steps,")
+                if end == -1:
+                    out.append(-100)
+                    continue
+                k = int(text[start:end])
+                turn = math.radians(min(max_turn_steps, k) * angle_per_step)
+                angle = turn if side == "left" else math.pi * 2.0 - turn
+                if "move" in text and k < max_turn_steps:
+                    s2 = text.find("move") + len("move")
+                    e2 = text.find("steps.")
+                    distance = int(text[s2:e2]) * distance_per_step
+                out.append((angle, distance))
+            except ValueError:
+                out.append(-100)
+        return out

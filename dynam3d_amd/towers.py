@@ -1,0 +1,281 @@
+"""The three dense towers of the step (the only true dense contractions, all on MFMA):
+
+  * `ClipVisionTower`  -- OpenAI CLIP ViT-L/14@336 image encoder returning (cls, 576 x 768 patch features)
+                          (reference: encoders/clip/model.py:202-238 `VisionTransformer`, driven by
+                          encoders/resnet_encoders.py:273-284 `CLIPEncoder.forward`), fp16 like the reference.
+  * `LlavaVisionTower` -- llava-phi-3-mini's HF CLIP vision model, hidden state of layer -2 without CLS,
+                          + 2-layer GELU projector -> (B,576,3072)   (VLN-POL:448-452), bf16.
+  * `Phi3Decoder`      -- Phi-3-mini decoder stack prefill over `inputs_embeds` -> logits at the last prompt
+                          position (VLN-POL:463), bf16.
+
+Weights arrive under the reference checkpoints' own key names (OpenAI CLIP `visual.*`, HF llava
+`vision_tower.*` / `multi_modal_projector.*` / `language_model.*`) and are re-laid-out once at load
+(fused QKV, contiguous [out,in]) for the GEMM kernels.  All matmuls/attention/norms go through
+`dense_ops`, which dispatches to the hand-written HIP kernels where they exist.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from . import dense_ops as D
+from .profiling import TIMER
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+@dataclass
+class VitConfig:
+    image: int = 336
+    patch: int = 14
+    width: int = 1024
+    layers: int = 24
+    heads: int = 16
+    mlp: int = 4096
+    out_dim: int = 768           # CLIP `proj`
+    proj_dim: int = 3072         # llava projector width
+
+    @property
+    def grid(self):
+        return self.image // self.patch
+
+    @property
+    def tokens(self):
+        return self.grid * self.grid + 1
+
+
+@dataclass
+class Phi3Config:
+    vocab: int = 32064
+    hidden: int = 3072
+    layers: int = 32
+    heads: int = 32
+    kv_heads: int = 32
+    mlp: int = 8192
+    rms_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    max_pos: int = 4096
+
+    @property
+    def head_dim(self):
+        return self.hidden // self.heads
+
+
+# ---------------------------------------------------------------------------------------------------
+# parameter specs (names == the reference checkpoints' keys)
+# ---------------------------------------------------------------------------------------------------
+def clip_param_spec(c: VitConfig):
+    s = [("visual.conv1.weight", (c.width, 3, c.patch, c.patch)), ("visual.class_embedding", (c.width,)),
+         ("visual.positional_embedding", (c.tokens, c.width)), ("visual.ln_pre.weight", (c.width,)), ("visual.ln_pre.bias", (c.width,))]
+    for i in range(c.layers):
+        p = f"visual.transformer.resblocks.{i}"
+        s += [(p + ".attn.in_proj_weight", (3 * c.width, c.width)), (p + ".attn.in_proj_bias", (3 * c.width,)),
+              (p + ".attn.out_proj.weight", (c.width, c.width)), (p + ".attn.out_proj.bias", (c.width,)),
+              (p + ".ln_1.weight", (c.width,)), (p + ".ln_1.bias", (c.width,)),
+              (p + ".mlp.c_fc.weight", (c.mlp, c.width)), (p + ".mlp.c_fc.bias", (c.mlp,)),
+              (p + ".mlp.c_proj.weight", (c.width, c.mlp)), (p + ".mlp.c_proj.bias", (c.width,)),
+              (p + ".ln_2.weight", (c.width,)), (p + ".ln_2.bias", (c.width,))]
+    s += [("visual.ln_post.weight", (c.width,)), ("visual.ln_post.bias", (c.width,)), ("visual.proj", (c.width, c.out_dim))]
+    return s
+
+
+def llava_vision_param_spec(c: VitConfig):
+    v = "vision_tower.vision_model"
+    s = [(v + ".embeddings.class_embedding", (c.width,)), (v + ".embeddings.patch_embedding.weight", (c.width, 3, c.patch, c.patch)),
+         (v + ".embeddings.position_embedding.weight", (c.tokens, c.width)),
+         (v + ".pre_layrnorm.weight", (c.width,)), (v + ".pre_layrnorm.bias", (c.width,))]
+    for i in range(c.layers):
+        p = f"{v}.encoder.layers.{i}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s += [(f"{p}.self_attn.{n}.weight", (c.width, c.width)), (f"{p}.self_attn.{n}.bias", (c.width,))]
+        s += [(p + ".layer_norm1.weight", (c.width,)), (p + ".layer_norm1.bias", (c.width,)),
+              (p + ".mlp.fc1.weight", (c.mlp, c.width)), (p + ".mlp.fc1.bias", (c.mlp,)),
+              (p + ".mlp.fc2.weight", (c.width, c.mlp)), (p + ".mlp.fc2.bias", (c.width,)),
+              (p + ".layer_norm2.weight", (c.width,)), (p + ".layer_norm2.bias", (c.width,))]
+    s += [("multi_modal_projector.linear_1.weight", (c.proj_dim, c.width)), ("multi_modal_projector.linear_1.bias", (c.proj_dim,)),
+          ("multi_modal_projector.linear_2.weight", (c.proj_dim, c.proj_dim)), ("multi_modal_projector.linear_2.bias", (c.proj_dim,))]
+    return s
+
+
+def phi3_param_spec(c: Phi3Config):
+    m = "language_model.model"
+    s = [(m + ".embed_tokens.weight", (c.vocab, c.hidden))]
+    qkv = (c.heads + 2 * c.kv_heads) * c.head_dim
+    for i in range(c.layers):
+        p = f"{m}.layers.{i}"
+        s += [(p + ".self_attn.qkv_proj.weight", (qkv, c.hidden)), (p + ".self_attn.o_proj.weight", (c.hidden, c.heads * c.head_dim)),
+              (p + ".mlp.gate_up_proj.weight", (2 * c.mlp, c.hidden)), (p + ".mlp.down_proj.weight", (c.hidden, c.mlp)),
+              (p + ".input_layernorm.weight", (c.hidden,)), (p + ".post_attention_layernorm.weight", (c.hidden,))]
+    s += [(m + ".norm.weight", (c.hidden,)), ("language_model.lm_head.weight", (c.vocab, c.hidden))]
+    return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# shared ViT trunk (pre-LN blocks, QuickGELU MLP): both CLIP flavours are this network
+# ---------------------------------------------------------------------------------------------------
+class _VitTrunk:
+    def __init__(self, cfg: VitConfig, dtype, device):
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.blocks = []
+        self.patch_w = self.cls = self.pos = None
+        self.ln_pre = None
+
+    def _t(self, x):
+        return x.detach().to(self.device, self.dtype).contiguous()
+
+    def _f(self, x):   # norm gains/biases and embeddings that are consumed in float32
+        return x.detach().to(self.device, torch.float32).contiguous()
+
+    def embed(self, pixels: torch.Tensor) -> torch.Tensor:
+        """pixels (B,3,336,336) normalised, tower dtype -> (B,577,width) after cls/pos/ln_pre."""
+        c = self.cfg
+        B = pixels.shape[0]
+        # conv14/stride14, no bias == GEMM over unfolded patches (B*576, 588) x (588, width)
+        pt = pixels.view(B, 3, c.grid, c.patch, c.grid, c.patch).permute(0, 2, 4, 1, 3, 5).reshape(B * c.grid * c.grid, 3 * c.patch * c.patch)
+        x = D.linear(pt, self.patch_w, None).view(B, c.grid * c.grid, c.width)
+        x = torch.cat([self.cls.expand(B, 1, c.width).to(x.dtype), x], dim=1) + self.pos.to(x.dtype)
+        return D.layer_norm(x, self.ln_pre[0], self.ln_pre[1], 1e-5)
+
+    def run_blocks(self, x: torch.Tensor, n_layers: int) -> torch.Tensor:
+        c = self.cfg
+        B, L, W = x.shape
+        for blk in self.blocks[:n_layers]:
+            h = D.layer_norm(x, blk["ln1_w"], blk["ln1_b"], 1e-5)
+            qkv = D.linear(h.view(B * L, W), blk["qkv_w"], blk["qkv_b"]).view(B, L, 3, c.heads, W // c.heads)
+            a = D.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal=False)         # (B,L,H,hd)
+            x = x + D.linear(a.reshape(B * L, W), blk["out_w"], blk["out_b"]).view(B, L, W)
+            h = D.layer_norm(x, blk["ln2_w"], blk["ln2_b"], 1e-5)
+            h = D.linear(h.view(B * L, W), blk["fc1_w"], blk["fc1_b"], act="quick_gelu")
+            x = x + D.linear(h, blk["fc2_w"], blk["fc2_b"]).view(B, L, W)
+        return x
+
+
+class ClipVisionTower(_VitTrunk):
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: VitConfig = VitConfig(), dtype=torch.float16, device="cuda"):
+        super().__init__(cfg, dtype, device)
+        t, f = self._t, self._f
+        self.patch_w = t(sd["visual.conv1.weight"].reshape(cfg.width, -1))
+        self.cls, self.pos = t(sd["visual.class_embedding"]), t(sd["visual.positional_embedding"])
+        self.ln_pre = (f(sd["visual.ln_pre.weight"]), f(sd["visual.ln_pre.bias"]))
+        self.ln_post = (f(sd["visual.ln_post.weight"]), f(sd["visual.ln_post.bias"]))
+        self.proj_w = t(sd["visual.proj"].t())          # stored [out,in] for D.linear
+        for i in range(cfg.layers):
+            p = f"visual.transformer.resblocks.{i}"
+            self.blocks.append(dict(
+                qkv_w=t(sd[p + ".attn.in_proj_weight"]), qkv_b=t(sd[p + ".attn.in_proj_bias"]),
+                out_w=t(sd[p + ".attn.out_proj.weight"]), out_b=t(sd[p + ".attn.out_proj.bias"]),
+                ln1_w=f(sd[p + ".ln_1.weight"]), ln1_b=f(sd[p + ".ln_1.bias"]), ln2_w=f(sd[p + ".ln_2.weight"]), ln2_b=f(sd[p + ".ln_2.bias"]),
+                fc1_w=t(sd[p + ".mlp.c_fc.weight"]), fc1_b=t(sd[p + ".mlp.c_fc.bias"]),
+                fc2_w=t(sd[p + ".mlp.c_proj.weight"]), fc2_b=t(sd[p + ".mlp.c_proj.bias"])))
+
+    @torch.no_grad()
+    def forward(self, pixels: torch.Tensor):
+        """-> (cls (B,768), patches (B,576,768)) in tower dtype (clip/model.py:219-238)."""
+        c = self.cfg
+        x = self.run_blocks(self.embed(pixels.to(self.dtype)), c.layers)
+        x = D.layer_norm(x, self.ln_post[0], self.ln_post[1], 1e-5)          # ln_post on ALL tokens
+        B, L, W = x.shape
+        y = D.linear(x.view(B * L, W), self.proj_w, None).view(B, L, c.out_dim)
+        return y[:, 0], y[:, 1:]
+
+
+class LlavaVisionTower(_VitTrunk):
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: VitConfig = VitConfig(), dtype=torch.bfloat16, device="cuda",
+                 feature_layer: int = -2):
+        super().__init__(cfg, dtype, device)
+        t, f = self._t, self._f
+        v = "vision_tower.vision_model"
+        self.patch_w = t(sd[v + ".embeddings.patch_embedding.weight"].reshape(cfg.width, -1))
+        self.cls, self.pos = t(sd[v + ".embeddings.class_embedding"]), t(sd[v + ".embeddings.position_embedding.weight"])
+        self.ln_pre = (f(sd[v + ".pre_layrnorm.weight"]), f(sd[v + ".pre_layrnorm.bias"]))
+        self.n_run = cfg.layers + 1 + feature_layer          # hidden_states[-2] == output of layer (L-1)
+        for i in range(cfg.layers):
+            p = f"{v}.encoder.layers.{i}.self_attn"
+            q = f"{v}.encoder.layers.{i}"
+            self.blocks.append(dict(
+                qkv_w=t(torch.cat([sd[p + ".q_proj.weight"], sd[p + ".k_proj.weight"], sd[p + ".v_proj.weight"]], 0)),
+                qkv_b=t(torch.cat([sd[p + ".q_proj.bias"], sd[p + ".k_proj.bias"], sd[p + ".v_proj.bias"]], 0)),
+                out_w=t(sd[p + ".out_proj.weight"]), out_b=t(sd[p + ".out_proj.bias"]),
+                ln1_w=f(sd[q + ".layer_norm1.weight"]), ln1_b=f(sd[q + ".layer_norm1.bias"]),
+                ln2_w=f(sd[q + ".layer_norm2.weight"]), ln2_b=f(sd[q + ".layer_norm2.bias"]),
+                fc1_w=t(sd[q + ".mlp.fc1.weight"]), fc1_b=t(sd[q + ".mlp.fc1.bias"]),
+                fc2_w=t(sd[q + ".mlp.fc2.weight"]), fc2_b=t(sd[q + ".mlp.fc2.bias"])))
+        self.p1 = (t(sd["multi_modal_projector.linear_1.weight"]), t(sd["multi_modal_projector.linear_1.bias"]))
+        self.p2 = (t(sd["multi_modal_projector.linear_2.weight"]), t(sd["multi_modal_projector.linear_2.bias"]))
+
+    @torch.no_grad()
+    def forward(self, pixels: torch.Tensor) -> torch.Tensor:
+        """-> (B,576,3072): llava.get_image_features(layer -2, 'default') (VLN-POL:448-452)."""
+        c = self.cfg
+        x = self.run_blocks(self.embed(pixels.to(self.dtype)), self.n_run)[:, 1:]
+        B, L, W = x.shape
+        h = D.linear(x.reshape(B * L, W), self.p1[0], self.p1[1], act="gelu")
+        return D.linear(h, self.p2[0], self.p2[1]).view(B, L, c.proj_dim)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Phi-3-mini decoder prefill
+# ---------------------------------------------------------------------------------------------------
+class Phi3Decoder:
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: Phi3Config = Phi3Config(), dtype=torch.bfloat16, device="cuda"):
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        t = lambda x: x.detach().to(self.device, dtype).contiguous()
+        f = lambda x: x.detach().to(self.device, torch.float32).contiguous()
+        m = "language_model.model"
+        self.embed_w = t(sd[m + ".embed_tokens.weight"])
+        self.layers = []
+        for i in range(cfg.layers):
+            p = f"{m}.layers.{i}"
+            self.layers.append(dict(qkv_w=t(sd[p + ".self_attn.qkv_proj.weight"]), o_w=t(sd[p + ".self_attn.o_proj.weight"]),
+                                    gu_w=t(sd[p + ".mlp.gate_up_proj.weight"]), down_w=t(sd[p + ".mlp.down_proj.weight"]),
+                                    n1=f(sd[p + ".input_layernorm.weight"]), n2=f(sd[p + ".post_attention_layernorm.weight"])))
+        self.norm_w = f(sd[m + ".norm.weight"])
+        self.lm_head_w = t(sd["language_model.lm_head.weight"])
+        self._rope_cache = {}
+
+    def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        return self.embed_w.index_select(0, ids.reshape(-1)).view(*ids.shape, self.cfg.hidden)
+
+    def _rope(self, S: int):
+        if S not in self._rope_cache:
+            c = self.cfg
+            inv = 1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.float32, device=self.device) / c.head_dim))
+            ang = torch.arange(S, dtype=torch.float32, device=self.device)[:, None] * inv[None]
+            self._rope_cache[S] = (ang.cos().contiguous(), ang.sin().contiguous())       # (S, hd/2) float32
+        return self._rope_cache[S]
+
+    @torch.no_grad()
+    def prefill_logits(self, inputs_embeds: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+        """inputs_embeds (B,S,3072) right-padded, lengths (B,) real lengths -> logits (B,vocab) float32 at the last
+        real position of each row.  Causal attention makes right padding invisible to real tokens."""
+        c = self.cfg
+        B, S, Hd = inputs_embeds.shape
+        x = inputs_embeds.to(self.dtype).contiguous()
+        cos, sin = self._rope(S)
+        for L in self.layers:
+            h = D.rms_norm(x, L["n1"], c.rms_eps)
+            qkv = D.linear(h.view(B * S, Hd), L["qkv_w"], None).view(B, S, c.heads + 2 * c.kv_heads, c.head_dim)
+            q, k, v = qkv[:, :, :c.heads], qkv[:, :, c.heads:c.heads + c.kv_heads], qkv[:, :, c.heads + c.kv_heads:]
+            q, k = D.rope(q, cos, sin), D.rope(k, cos, sin)
+            a = D.attention(q, k, v, causal=True)
+            x = x + D.linear(a.reshape(B * S, c.heads * c.head_dim), L["o_w"], None).view(B, S, Hd)
+            h = D.rms_norm(x, L["n2"], c.rms_eps)
+            with TIMER.range("phi3.gate_up_proj"):
+                gu = D.linear(h.view(B * S, Hd), L["gu_w"], None)
+            x = x + D.linear(D.swiglu(gu), L["down_w"], None).view(B, S, Hd)
+        last = x[torch.arange(B, device=x.device), (lengths.to(x.device).long() - 1)]
+        last = D.rms_norm(last, self.norm_w, c.rms_eps)
+        return D.linear(last, self.lm_head_w, None).float()
+
+
+# ---------------------------------------------------------------------------------------------------
+# image preprocessing shared by both towers (a3: resnet_encoders.py:267-271)
+# ---------------------------------------------------------------------------------------------------
+def preprocess_rgb(rgb_u8: torch.Tensor, size: int = 336) -> torch.Tensor:
+    """rgb (B,h,w,3) uint8 -> (B,3,336,336) float32 normalised: CHW, bicubic resize in float with the result
+    rounded back to uint8 (torchvision's tensor path), /255, CLIP mean/std."""
+    return D.resize_normalize(rgb_u8, size, CLIP_MEAN, CLIP_STD)

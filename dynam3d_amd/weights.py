@@ -22,10 +22,16 @@ def _name_seed(seed: int, name: str) -> int:
     return int.from_bytes(h[:8], "little") & 0x7FFF_FFFF_FFFF_FFFF
 
 
-def make_tensor(seed: int, name: str, shape: Tuple[int, ...], kind: str = "auto", fan_in: int | None = None) -> torch.Tensor:
-    """kind: 'linear' (N(0, fan_in^-1/2)), 'bias' (N(0,0.02)), 'norm_w' (1+N(0,0.02)), 'embed' (N(0, d^-1/2))."""
-    g = torch.Generator(device="cpu")
+def make_tensor(seed: int, name: str, shape: Tuple[int, ...], kind: str = "auto", fan_in: int | None = None,
+                device: str = "cpu") -> torch.Tensor:
+    """kind: 'linear' (N(0, fan_in^-1/2)), 'bias' (N(0,0.02)), 'norm_w' (1+N(0,0.02)), 'embed' (N(0, d^-1/2)).
+    device='cpu' values are the cross-machine reproducible ones used for parity; device='cuda' draws from the
+    GPU generator (different numbers, same distribution) and exists so the 4.4 B-parameter benchmark model
+    does not spend a minute in a single-threaded host RNG."""
+    g = torch.Generator(device=device)
     g.manual_seed(_name_seed(seed, name))
+    _randn = torch.randn
+    torch_randn = lambda shape, generator, dtype: _randn(shape, generator=generator, dtype=dtype, device=device)
     if kind == "auto":
         if name.endswith("bias"):
             kind = "bias"
@@ -35,13 +41,13 @@ def make_tensor(seed: int, name: str, shape: Tuple[int, ...], kind: str = "auto"
             kind = "linear"
     if kind == "linear":
         fi = fan_in if fan_in is not None else int(torch.tensor(shape[1:]).prod().item())
-        return torch.randn(shape, generator=g, dtype=torch.float32) * (fi ** -0.5)
+        return torch_randn(shape, generator=g, dtype=torch.float32) * (fi ** -0.5)
     if kind == "bias":
-        return torch.randn(shape, generator=g, dtype=torch.float32) * 0.02
+        return torch_randn(shape, generator=g, dtype=torch.float32) * 0.02
     if kind == "norm_w":
-        return 1.0 + torch.randn(shape, generator=g, dtype=torch.float32) * 0.02
+        return 1.0 + torch_randn(shape, generator=g, dtype=torch.float32) * 0.02
     if kind == "embed":
-        return torch.randn(shape, generator=g, dtype=torch.float32) * (shape[-1] ** -0.5)
+        return torch_randn(shape, generator=g, dtype=torch.float32) * (shape[-1] ** -0.5)
     raise ValueError(kind)
 
 
@@ -51,7 +57,8 @@ def _is_norm(name: str) -> bool:
                for p in parts)
 
 
-def synth_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0, norm_names: Iterable[str] = ()) -> Dict[str, torch.Tensor]:
+def synth_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0, norm_names: Iterable[str] = (),
+                     device: str = "cpu", dtype_for=None) -> Dict[str, torch.Tensor]:
     """spec: iterable of (name, shape).  1-D '...weight' tensors are norm gains, 1-D '...bias' are
     biases, >=2-D are linear/conv/embedding matrices."""
     out = {}
@@ -66,14 +73,16 @@ def synth_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0,
             kind = "embed"
         else:
             kind = "linear"
-        out[name] = make_tensor(seed, name, shape, kind)
+        out[name] = make_tensor(seed, name, shape, kind, device=device)
+        if dtype_for is not None:
+            out[name] = out[name].to(dtype_for(name))
         if name == "instance_merge_discriminator.0.weight":
             # synthetic-only: make the merge decision depend visibly on the 3-d position offset so
             # seeded episodes exercise BOTH the "new instance" and the "merge" branch (with plain
             # random weights the LayerNorm'ed features give near-constant logits).
             out[name][:, -3:] *= 160.0
         if name == "instance_merge_discriminator.3.bias":
-            out[name] += torch.tensor([0.4, -0.4])   # ~25 % positive proposals on the synthetic episodes
+            out[name] += torch.tensor([0.4, -0.4], device=out[name].device)   # ~25 % positive proposals on the synthetic episodes
     return out
 
 

@@ -1,0 +1,72 @@
+"""Whole-step CPU oracle: posed RGB-D -> 3D tokens -> prefix -> Phi-3 prefill -> logits at the last prompt
+position, float32 (VLN-POL:329-363, 430-463 restated on top of the pinned pieces: oracle/geometry.py,
+ff_oracle.py, towers_ref.py).  TEST INFRASTRUCTURE; also the `cpu_baseline` leg of bench.py ("port")."""
+from __future__ import annotations
+
+import time
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from . import geometry as G
+from . import towers_ref as TR
+from .ff_oracle import FeatureFieldsOracle
+
+
+class StepOracle:
+    def __init__(self, sd: Dict[str, torch.Tensor], vit_cfg, llm_cfg, batch_size: int, tokenizer, depth_scale=(0.0, 10.0)):
+        self.sd, self.vit, self.llm, self.tok = sd, vit_cfg, llm_cfg, tokenizer
+        self.ff = FeatureFieldsOracle(sd, batch_size)
+        self.history = [["none\n"] * 4 for _ in range(batch_size)]
+        self.depth_scale = depth_scale
+        self.timing = {}
+
+    @torch.no_grad()
+    def build_inputs(self, rgb: np.ndarray, depth: np.ndarray, instructions: List[str], positions, headings, patch_segm):
+        B = rgb.shape[0]
+        t0 = time.time()
+        d24 = G.preprocess_depth(G.downsample_depth_nearest(depth), self.depth_scale).reshape(B, 1, -1)     # VLN-POL:336-341 (F9 fixed)
+        px = TR.preprocess_rgb(rgb, self.vit.image)
+        _, grid = TR.clip_vit_forward(px, self.sd, self.vit.layers, self.vit.heads, self.vit.patch)         # VLN-POL:344
+        t1 = time.time()
+        dfull = G.preprocess_depth(depth, self.depth_scale)[..., 0]
+        self.ff.delete_old_features_from_camera_frustum(dfull.reshape(B, 1, *dfull.shape[1:]), positions, headings)   # VLN-POL:351
+        self.ff.update_feature_fields(d24, grid.numpy().reshape(B, 1, *grid.shape[1:]), patch_segm, positions, headings)  # VLN-POL:354
+        env = self.ff.get_environment_features(positions, headings)
+        info = self.ff.get_patch_3d_info(d24.reshape(B, -1))
+        rx, ry, rz, dr, sc = (torch.from_numpy(np.ascontiguousarray(a)) for a in info)
+        info6 = torch.cat([rx, ry, rz, torch.sin(dr), torch.cos(dr), sc], -1)
+        cat = lambda xs, w: torch.from_numpy(np.concatenate(xs).reshape(-1, w).astype(np.float32))
+        patch_pos, inst_tok, zone_tok = TR.prefix_tokens(info6, cat(env["batch_instance_fts"], 768), cat(env["batch_instance_relative_position"], 3),
+                                                         cat(env["batch_zone_fts"], 768), cat(env["batch_zone_relative_position"], 3), self.sd)
+        t2 = time.time()
+        patch_tok = TR.llava_image_features(px, self.sd, self.vit.layers, self.vit.heads, self.vit.patch) + patch_pos       # VLN-POL:448-453
+        t3 = time.time()
+        emb_w = self.sd["language_model.model.embed_tokens.weight"].float()
+        head = emb_w[torch.tensor(self.tok.encode("<|user|>", bos=True))]
+        ni = [len(x) for x in env["batch_instance_fts"]]
+        nz = [len(x) for x in env["batch_zone_fts"]]
+        io, zo = np.concatenate([[0], np.cumsum(ni)]), np.concatenate([[0], np.cumsum(nz)])
+        rows = []
+        for b in range(B):
+            text = ("\nInstruction:\n" + instructions[b] + "\nHistory actions:\n" + "".join(self.history[b]) + "<|end|>\n<|assistant|>\nNext action:\n")
+            te = emb_w[torch.tensor(self.tok.encode(text))]
+            rows.append(torch.cat([head, patch_tok[b], inst_tok[io[b]:io[b + 1]], zone_tok[zo[b]:zo[b + 1]], te], 0))     # VLN-POL:456
+        lengths = [r.shape[0] for r in rows]
+        emb = torch.zeros(B, max(lengths), emb_w.shape[1])
+        for b, r in enumerate(rows):
+            emb[b, :lengths[b]] = r
+        self.timing.update(vit_clip=t1 - t0, tokens_3d=t2 - t1, vit_llava=t3 - t2)
+        self.counts = dict(Ni=ni, Nz=nz)
+        return emb, lengths
+
+    @torch.no_grad()
+    def forward_logits(self, rgb, depth, instructions, positions, headings, patch_segm) -> np.ndarray:
+        emb, lengths = self.build_inputs(rgb, depth, instructions, positions, headings, patch_segm)
+        t0 = time.time()
+        c = self.llm
+        lo = TR.phi3_prefill_logits(emb, lengths, self.sd, c.layers, c.heads, c.kv_heads, c.rms_eps, c.rope_theta)
+        self.timing["phi3_prefill"] = time.time() - t0
+        self.last_embeds, self.last_lengths = emb, lengths
+        return lo.numpy()

@@ -1,0 +1,152 @@
+"""Float32 CPU restatement of the dense towers on the step path.  TEST INFRASTRUCTURE (see
+oracle/geometry.py header).
+
+  * clip_vit_forward      <- encoders/clip/model.py:162-238 (QuickGELU, ResidualAttentionBlock, VisionTransformer)
+                             + encoders/resnet_encoders.py:267-284 (CLIPEncoder preprocessing)
+  * llava_image_features  <- VLN-POL:448-452 `llava.get_image_features(layer -2, 'default')`; the HF CLIP vision
+                             model / projector arithmetic is third-party (`transformers==4.46.0`, not vendored):
+                             pinned against the installed transformers' CLIPVisionModel on seeded small configs
+  * phi3_prefill_logits   <- VLN-POL:463 (llava.generate -> first-token logits); Phi-3 arithmetic pinned against the
+                             installed transformers' Phi3ForCausalLM on seeded small configs
+  * prefix MLPs / splice  <- VLN-POL:432-461
+Pinning scripts: tests/golden/gen_golden_dense.py (goldens g5, g8, g9).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import nnref as NN
+
+T = torch.Tensor
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def preprocess_rgb(rgb_u8: np.ndarray, size: int = 336) -> T:
+    """(B,h,w,3) uint8 -> (B,3,size,size) f32.  torchvision Resize(bicubic) on a uint8 tensor interpolates in
+    float and rounds back to uint8; ConvertImageDtype(float) divides by 255; Normalize (resnet_encoders.py:267-271)."""
+    x = torch.from_numpy(np.ascontiguousarray(rgb_u8)).permute(0, 3, 1, 2).float()
+    if x.shape[-1] != size or x.shape[-2] != size:
+        x = F.interpolate(x, size=(size, size), mode="bicubic", align_corners=False).round().clamp(0, 255)
+    x = x / 255.0
+    m, s = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    return (x - m) / s
+
+
+def _vit_blocks(x: T, get, n_layers: int, heads: int) -> T:
+    """Pre-LN residual blocks with QuickGELU MLP; `get(i, name)` returns the (fused-qkv) tensors."""
+    B, L, W = x.shape
+    hd = W // heads
+    for i in range(n_layers):
+        h = F.layer_norm(x, (W,), get(i, "ln1_w"), get(i, "ln1_b"), 1e-5)
+        qkv = F.linear(h, get(i, "qkv_w"), get(i, "qkv_b")).view(B, L, 3, heads, hd)
+        q, k, v = (qkv[:, :, j].transpose(1, 2) for j in range(3))
+        att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)
+        a = (att @ v).transpose(1, 2).reshape(B, L, W)
+        x = x + F.linear(a, get(i, "out_w"), get(i, "out_b"))
+        h = F.layer_norm(x, (W,), get(i, "ln2_w"), get(i, "ln2_b"), 1e-5)
+        h = F.linear(h, get(i, "fc1_w"), get(i, "fc1_b"))
+        h = h * torch.sigmoid(1.702 * h)
+        x = x + F.linear(h, get(i, "fc2_w"), get(i, "fc2_b"))
+    return x
+
+
+def _embed(pixels: T, patch_w: T, cls: T, pos: T, patch: int) -> T:
+    x = F.conv2d(pixels, patch_w, stride=patch)
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat([cls.view(1, 1, -1).expand(x.shape[0], 1, -1), x], 1)
+    return x + pos
+
+
+def clip_vit_forward(pixels: T, sd: Dict[str, T], layers: int, heads: int, patch: int = 14):
+    p = "visual."
+    names = dict(ln1_w="ln_1.weight", ln1_b="ln_1.bias", ln2_w="ln_2.weight", ln2_b="ln_2.bias", qkv_w="attn.in_proj_weight",
+                 qkv_b="attn.in_proj_bias", out_w="attn.out_proj.weight", out_b="attn.out_proj.bias", fc1_w="mlp.c_fc.weight",
+                 fc1_b="mlp.c_fc.bias", fc2_w="mlp.c_proj.weight", fc2_b="mlp.c_proj.bias")
+    get = lambda i, n: sd[f"{p}transformer.resblocks.{i}.{names[n]}"].float()
+    x = _embed(pixels, sd[p + "conv1.weight"].float(), sd[p + "class_embedding"].float(), sd[p + "positional_embedding"].float(), patch)
+    W = x.shape[-1]
+    x = F.layer_norm(x, (W,), sd[p + "ln_pre.weight"].float(), sd[p + "ln_pre.bias"].float(), 1e-5)
+    x = _vit_blocks(x, get, layers, heads)
+    x = F.layer_norm(x, (W,), sd[p + "ln_post.weight"].float(), sd[p + "ln_post.bias"].float(), 1e-5)
+    y = x @ sd[p + "proj"].float()
+    return y[:, 0], y[:, 1:]
+
+
+def llava_image_features(pixels: T, sd: Dict[str, T], layers: int, heads: int, patch: int = 14, feature_layer: int = -2) -> T:
+    v = "vision_tower.vision_model."
+
+    def get(i, n):
+        q = f"{v}encoder.layers.{i}."
+        if n == "qkv_w":
+            return torch.cat([sd[q + f"self_attn.{x}_proj.weight"] for x in "qkv"], 0).float()
+        if n == "qkv_b":
+            return torch.cat([sd[q + f"self_attn.{x}_proj.bias"] for x in "qkv"], 0).float()
+        m = dict(ln1_w="layer_norm1.weight", ln1_b="layer_norm1.bias", ln2_w="layer_norm2.weight", ln2_b="layer_norm2.bias",
+                 out_w="self_attn.out_proj.weight", out_b="self_attn.out_proj.bias", fc1_w="mlp.fc1.weight", fc1_b="mlp.fc1.bias",
+                 fc2_w="mlp.fc2.weight", fc2_b="mlp.fc2.bias")
+        return sd[q + m[n]].float()
+
+    x = _embed(pixels, sd[v + "embeddings.patch_embedding.weight"].float(), sd[v + "embeddings.class_embedding"].float(),
+               sd[v + "embeddings.position_embedding.weight"].float(), patch)
+    W = x.shape[-1]
+    x = F.layer_norm(x, (W,), sd[v + "pre_layrnorm.weight"].float(), sd[v + "pre_layrnorm.bias"].float(), 1e-5)
+    x = _vit_blocks(x, get, layers + 1 + feature_layer, heads)[:, 1:]
+    h = F.gelu(F.linear(x, sd["multi_modal_projector.linear_1.weight"].float(), sd["multi_modal_projector.linear_1.bias"].float()))
+    return F.linear(h, sd["multi_modal_projector.linear_2.weight"].float(), sd["multi_modal_projector.linear_2.bias"].float())
+
+
+def phi3_prefill_logits(embeds: T, lengths: Sequence[int], sd: Dict[str, T], layers: int, heads: int, kv_heads: int,
+                        rms_eps: float = 1e-5, theta: float = 10000.0) -> T:
+    """embeds (B,S,H) right-padded f32 -> logits (B,vocab) at position lengths[b]-1."""
+    m = "language_model.model."
+    B, S, H = embeds.shape
+    hd = H // heads
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    ang = torch.arange(S, dtype=torch.float32)[:, None] * inv[None]
+    cos, sin = torch.cat([ang.cos(), ang.cos()], -1), torch.cat([ang.sin(), ang.sin()], -1)
+
+    def rms(x, w):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + rms_eps) * w.float()
+
+    def rot(x):   # (B,h,S,hd)
+        x1, x2 = x[..., : hd // 2], x[..., hd // 2:]
+        return x * cos + torch.cat([-x2, x1], -1) * sin
+
+    causal = torch.ones(S, S, dtype=torch.bool).tril()
+    x = embeds.float()
+    for i in range(layers):
+        p = f"{m}layers.{i}."
+        h = rms(x, sd[p + "input_layernorm.weight"])
+        qkv = F.linear(h, sd[p + "self_attn.qkv_proj.weight"].float())
+        q = qkv[..., : heads * hd].view(B, S, heads, hd).transpose(1, 2)
+        k = qkv[..., heads * hd: (heads + kv_heads) * hd].view(B, S, kv_heads, hd).transpose(1, 2)
+        v = qkv[..., (heads + kv_heads) * hd:].view(B, S, kv_heads, hd).transpose(1, 2)
+        q, k = rot(q), rot(k)
+        if kv_heads != heads:
+            k, v = k.repeat_interleave(heads // kv_heads, 1), v.repeat_interleave(heads // kv_heads, 1)
+        att = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+        att = torch.softmax(att.masked_fill(~causal, float("-inf")), -1)
+        a = (att @ v).transpose(1, 2).reshape(B, S, heads * hd)
+        x = x + F.linear(a, sd[p + "self_attn.o_proj.weight"].float())
+        h = rms(x, sd[p + "post_attention_layernorm.weight"])
+        gu = F.linear(h, sd[p + "mlp.gate_up_proj.weight"].float())
+        g, u = gu.chunk(2, -1)
+        x = x + F.linear(u * F.silu(g), sd[p + "mlp.down_proj.weight"].float())
+    last = x[torch.arange(B), torch.as_tensor(lengths) - 1]
+    return F.linear(rms(last, sd[m + "norm.weight"]), sd["language_model.lm_head.weight"].float())
+
+
+def prefix_tokens(info6: T, ifts: T, irel: T, zfts: T, zrel: T, sd: Dict[str, T]):
+    """VLN-POL:432-435.  info6 (N,576,6) = [x,y,z,sin d,cos d,scale]."""
+    f = {k: v.float() for k, v in sd.items() if k.split(".")[0] in ("patch_position_embedding", "instance_position_embedding",
+                                                                     "zone_position_embedding", "instance_projector", "zone_projector")}
+    patch = NN.mlp_ln_gelu(info6, f, "patch_position_embedding")
+    inst = NN.mlp_ln_gelu(torch.cat([ifts, NN.mlp_ln_gelu(irel, f, "instance_position_embedding")], -1), f, "instance_projector")
+    zone = NN.mlp_ln_gelu(torch.cat([zfts, NN.mlp_ln_gelu(zrel, f, "zone_position_embedding")], -1), f, "zone_projector")
+    return patch, inst, zone
