@@ -1,0 +1,278 @@
+// dense_kernels.hip -- HBM-bound row kernels around the GEMMs: LayerNorm / RMSNorm (fp32 statistics,
+// 16-byte vector loads, one wave per row, the row held in registers: one read + one write per element),
+// in-place half-split RoPE on the fused QKV buffer, and the bicubic resize + normalise front-end.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/dynam3d_hip.h"
+#include "d3d_common.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+
+template <bool BF16>
+__device__ __forceinline__ float ld16(uint16_t v) {
+    if constexpr (BF16) return __uint_as_float((uint32_t)v << 16);
+    else return __half2float(*reinterpret_cast<const __half*>(&v));
+}
+template <bool BF16>
+__device__ __forceinline__ uint16_t st16(float f) {
+    if constexpr (BF16) {
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    } else {
+        __half h = __float2half_rn(f);
+        return *reinterpret_cast<uint16_t*>(&h);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wave per row; D = 512*NCH elements (8 per lane per chunk).  RMS: y = x * rsqrt(mean(x^2)+eps) * w.
+// LN: y = (x-mean) * rsqrt(var+eps) * w + b   (biased variance, float32, like F.layer_norm on x.float()).
+template <bool BF16, bool RMS, int NCH>
+__global__ void __launch_bounds__(256)
+k_norm(const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, uint16_t* __restrict__ y,
+       int rows, int D, int64_t ldx, int64_t ldy, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const uint16_t* xr = x + (int64_t)row * ldx;
+    float v[NCH][8];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int off = c * 512 + lane * 8;
+        if (off < D) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(xr + off);
+            const uint16_t* h = reinterpret_cast<const uint16_t*>(&raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[c][j] = ld16<BF16>(h[j]);
+                s += v[c][j];
+                ss += v[c][j] * v[c][j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+        }
+    }
+    float mean = 0.f, rstd;
+    if constexpr (RMS) {
+        ss = wave_sum(ss);
+        rstd = rsqrtf(ss / (float)D + eps);
+    } else {
+        s = wave_sum(s);
+        mean = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c * 512 + lane * 8 < D) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = v[c][j] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / (float)D + eps);
+    }
+    uint16_t* yr = y + (int64_t)row * ldy;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int off = c * 512 + lane * 8;
+        if (off < D) {
+            const float4 w0 = *reinterpret_cast<const float4*>(w + off), w1 = *reinterpret_cast<const float4*>(w + off + 4);
+            const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            float bb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (!RMS) {
+                const float4 b0 = *reinterpret_cast<const float4*>(b + off), b1 = *reinterpret_cast<const float4*>(b + off + 4);
+                bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+            }
+            uint16_t o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = st16<BF16>((v[c][j] - mean) * rstd * ww[j] + bb[j]);
+            *reinterpret_cast<uint4*>(yr + off) = *reinterpret_cast<const uint4*>(o);
+        }
+    }
+}
+
+// In-place half-split RoPE over the first `n_rot_heads` heads of every row of the fused QKV buffer
+// (q heads then k heads are contiguous in Phi-3's qkv_proj output).  pos = row % S.
+template <bool BF16>
+__global__ void k_rope(uint16_t* __restrict__ qkv, const float* __restrict__ cos_t, const float* __restrict__ sin_t, int rows,
+                       int S, int n_rot_heads, int hd, int64_t ld) {
+    const int half = hd >> 1;
+    const int per_row = n_rot_heads * half;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * per_row) return;
+    const int row = (int)(i / per_row), r = (int)(i % per_row);
+    const int h = r / half, p = r % half;
+    const int pos = row % S;
+    uint16_t* base = qkv + (int64_t)row * ld + h * hd;
+    const float x1 = ld16<BF16>(base[p]), x2 = ld16<BF16>(base[p + half]);
+    const float c = cos_t[pos * half + p], s = sin_t[pos * half + p];
+    base[p] = st16<BF16>(x1 * c - x2 * s);
+    base[p + half] = st16<BF16>(x2 * c + x1 * s);
+}
+
+// Bicubic (A = -0.75, align_corners = False, border-clamped taps) resize of uint8 HWC images to SxS, result
+// rounded back to uint8 (torchvision tensor path), /255, (x-mean)/std -> float CHW.
+__device__ __forceinline__ void cubic_w(float t, float* w) {
+    const float A = -0.75f;
+    float x = t + 1.0f;
+    w[0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+    x = t;
+    w[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 1.0f - t;
+    w[2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 2.0f - t;
+    w[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+}
+
+__global__ void k_resize_normalize(const uint8_t* __restrict__ rgb, float* __restrict__ out, int B, int H, int W, int S,
+                                   float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * S * S) return;
+    const int b = (int)(i / (S * S)), oy = (int)((i / S) % S), ox = (int)(i % S);
+    const uint8_t* img = rgb + (int64_t)b * H * W * 3;
+    float val[3];
+    if (H == S && W == S) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) val[c] = (float)img[((int64_t)oy * W + ox) * 3 + c];
+    } else {
+        const float sy = (float)H / (float)S, sx = (float)W / (float)S;
+        const float fy = sy * ((float)oy + 0.5f) - 0.5f, fx = sx * ((float)ox + 0.5f) - 0.5f;
+        const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+        float wy[4], wx[4];
+        cubic_w(fy - (float)iy, wy);
+        cubic_w(fx - (float)ix, wx);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int yy = min(max(iy - 1 + a, 0), H - 1);
+                float rowv = 0.f;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int xx = min(max(ix - 1 + d, 0), W - 1);
+                    rowv += (float)img[((int64_t)yy * W + xx) * 3 + c] * wx[d];
+                }
+                acc += rowv * wy[a];
+            }
+            val[c] = fminf(fmaxf(rintf(acc), 0.f), 255.f);
+        }
+    }
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[(((int64_t)b * 3 + c) * S + oy) * S + ox] = (val[c] / 255.0f - mean[c]) / stdv[c];
+}
+
+// SwiGLU over a plain [gate | up] projection output: out[m, i] = up * silu(gate); 8 elements per thread.
+template <bool BF16>
+__global__ void k_swiglu(const uint16_t* __restrict__ gu, uint16_t* __restrict__ out, int64_t rows, int I) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= rows * I) return;
+    const int64_t r = i / I;
+    const int c = (int)(i % I);
+    const uint4 g = *reinterpret_cast<const uint4*>(gu + r * 2 * I + c);
+    const uint4 u = *reinterpret_cast<const uint4*>(gu + r * 2 * I + I + c);
+    const uint16_t* gh = reinterpret_cast<const uint16_t*>(&g);
+    const uint16_t* uh = reinterpret_cast<const uint16_t*>(&u);
+    uint16_t o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float gv = ld16<BF16>(gh[j]);
+        o[j] = st16<BF16>(ld16<BF16>(uh[j]) * (gv / (1.0f + __expf(-gv))));
+    }
+    *reinterpret_cast<uint4*>(out + i) = *reinterpret_cast<const uint4*>(o);
+}
+
+template <bool BF16, bool RMS>
+int32_t launch_norm(const void* x, const float* w, const float* b, void* y, int rows, int D, int64_t ldx, int64_t ldy, float eps,
+                    hipStream_t s) {
+    const int nch = (D + 511) / 512;
+    dim3 grid((rows + 3) / 4), block(256);
+#define D3D_NORM_CASE(N)                                                                                                       \
+    case N:                                                                                                                    \
+        hipLaunchKernelGGL((k_norm<BF16, RMS, N>), grid, block, 0, s, (const uint16_t*)x, w, b, (uint16_t*)y, rows, D, ldx, ldy, eps); \
+        break;
+    switch (nch) {
+        D3D_NORM_CASE(1)
+        D3D_NORM_CASE(2)
+        D3D_NORM_CASE(3)
+        D3D_NORM_CASE(4)
+        D3D_NORM_CASE(6)
+        D3D_NORM_CASE(8)
+        default:
+            d3d_set_error_("d3d_norm: unsupported width (need D <= 4096 with ceil(D/512) in {1,2,3,4,6,8})");
+            return D3D_EINVAL;
+    }
+#undef D3D_NORM_CASE
+    D3D_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+extern "C" {
+
+// y = LayerNorm(x) (rms == 0) or RMSNorm(x) (rms == 1); x,y bf16 (dtype 0) / fp16 (dtype 1) rows of D (D % 8 == 0), fp32 w[,b].
+int32_t d3d_norm(const void* x, const float* w, const float* b, void* y, int32_t rows, int32_t D, int64_t ldx, int64_t ldy,
+                 float eps, int32_t rms, int32_t dtype, void* stream) {
+    if (rows <= 0) return D3D_OK;
+    if (D % 8 != 0 || (ldx & 7) || (ldy & 7)) {
+        d3d_set_error_("d3d_norm: D, ldx, ldy must be multiples of 8");
+        return D3D_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == 0) return rms ? launch_norm<true, true>(x, w, b, y, rows, D, ldx, ldy, eps, s) : launch_norm<true, false>(x, w, b, y, rows, D, ldx, ldy, eps, s);
+    return rms ? launch_norm<false, true>(x, w, b, y, rows, D, ldx, ldy, eps, s) : launch_norm<false, false>(x, w, b, y, rows, D, ldx, ldy, eps, s);
+}
+
+int32_t d3d_rope_inplace(void* qkv, const float* cos_t, const float* sin_t, int32_t rows, int32_t S, int32_t n_rot_heads,
+                         int32_t head_dim, int64_t ld, int32_t dtype, void* stream) {
+    if (rows <= 0) return D3D_OK;
+    const int64_t n = (int64_t)rows * n_rot_heads * (head_dim / 2);
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_rope<true>, grid, block, 0, (hipStream_t)stream, (uint16_t*)qkv, cos_t, sin_t, rows, S, n_rot_heads, head_dim, ld);
+    else
+        hipLaunchKernelGGL(k_rope<false>, grid, block, 0, (hipStream_t)stream, (uint16_t*)qkv, cos_t, sin_t, rows, S, n_rot_heads, head_dim, ld);
+    D3D_LAUNCH_CHECK();
+}
+
+int32_t d3d_swiglu(const void* gate_up, void* out, int64_t rows, int32_t I, int32_t dtype, void* stream) {
+    if (rows <= 0) return D3D_OK;
+    if (I % 8) {
+        d3d_set_error_("d3d_swiglu: I must be a multiple of 8");
+        return D3D_EINVAL;
+    }
+    const int64_t n = rows * I / 8;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_swiglu<true>, grid, block, 0, (hipStream_t)stream, (const uint16_t*)gate_up, (uint16_t*)out, rows, I);
+    else
+        hipLaunchKernelGGL(k_swiglu<false>, grid, block, 0, (hipStream_t)stream, (const uint16_t*)gate_up, (uint16_t*)out, rows, I);
+    D3D_LAUNCH_CHECK();
+}
+
+int32_t d3d_resize_normalize(const uint8_t* rgb, float* out, int32_t B, int32_t H, int32_t W, int32_t S, const float* mean3_h,
+                             const float* std3_h, void* stream) {
+    if (B <= 0) return D3D_OK;
+    const int64_t n = (int64_t)B * S * S;
+    hipLaunchKernelGGL(k_resize_normalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rgb, out, B, H, W, S,
+                       mean3_h[0], mean3_h[1], mean3_h[2], std3_h[0], std3_h[1], std3_h[2]);
+    D3D_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -42,21 +42,39 @@ def _act(y, act):
     raise ValueError(act)
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: Optional[str] = None) -> torch.Tensor:
-    if BACKEND["linear"] == "hip" and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16):
-        return _hip.linear(x, w, b, act)
-    return _act(F.linear(x, w, b), act)
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: Optional[str] = None,
+           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = act(x w^T + b) [+ residual].  x (M,K), w (N,K).  On the HIP backend bias / activation / residual are
+    fused into the GEMM epilogue (csrc/gemm_kernels.hip)."""
+    if BACKEND["linear"] == "hip" and x.is_cuda and _hip.gemm_ok(x, w):
+        return _hip.linear(x, w, b, act, residual)
+    y = _act(F.linear(x, w, b), act)
+    return y if residual is None else y + residual.reshape(y.shape)
+
+
+def linear_swiglu(x: torch.Tensor, w_gate_up: torch.Tensor, interleaved: bool) -> torch.Tensor:
+    """Phi-3 MLP front half: up * silu(gate) of x w^T.  `interleaved` says whether w's rows were re-laid-out by
+    hip_dense.interleave_gate_up (per-16 gate/up blocks) for the fused-epilogue kernel."""
+    if interleaved and BACKEND["linear"] == "hip" and x.is_cuda and _hip.gemm_ok(x, w_gate_up):
+        return _hip.linear_swiglu(x, w_gate_up)
+    gu = F.linear(x, w_gate_up)
+    if interleaved:
+        I = gu.shape[-1] // 2
+        gu = gu.view(-1, I // 16, 2, 16)
+        g, u = gu[:, :, 0].reshape(-1, I), gu[:, :, 1].reshape(-1, I)
+        return (u.float() * F.silu(g.float())).to(x.dtype)
+    return swiglu(gu)
 
 
 def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
     """float32 statistics and affine, result in x.dtype (clip/model.py:153-159)."""
-    if BACKEND["layer_norm"] == "hip" and x.is_cuda:
+    if BACKEND["layer_norm"] == "hip" and x.is_cuda and _hip.norm_ok(x):
         return _hip.layer_norm(x, w, b, eps)
     return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps).to(x.dtype)
 
 
 def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
-    if BACKEND["rms_norm"] == "hip" and x.is_cuda:
+    if BACKEND["rms_norm"] == "hip" and x.is_cuda and _hip.norm_ok(x):
         return _hip.rms_norm(x, w, eps)
     xf = x.float()
     return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * w).to(x.dtype)
@@ -70,10 +88,18 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool) -
     return o.transpose(1, 2).contiguous()
 
 
+def rope_qk_(qkv: torch.Tensor, n_rot_heads: int, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """Rotate the first `n_rot_heads` heads (q heads then k heads) of the fused projection qkv (B,S,Htot,hd);
+    in place on the HIP backend (one pass over q,k instead of slice/float/cat round trips)."""
+    B, S, Ht, hd = qkv.shape
+    if BACKEND["rope"] == "hip" and qkv.is_cuda and qkv.is_contiguous() and qkv.dtype in (torch.bfloat16, torch.float16):
+        _hip.rope_inplace(qkv.view(B * S, Ht * hd), cos, sin, S, n_rot_heads, hd)
+        return qkv
+    return torch.cat([rope(qkv[:, :, :n_rot_heads], cos, sin), qkv[:, :, n_rot_heads:]], dim=2)
+
+
 def rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
     """Half-split rotary embedding (HF `rotate_half`): pairs (i, i+hd/2).  x (B,S,H,hd); cos/sin (S,hd/2) f32."""
-    if BACKEND["rope"] == "hip" and x.is_cuda:
-        return _hip.rope(x, cos, sin)
     hd = x.shape[-1]
     x1, x2 = x[..., : hd // 2].float(), x[..., hd // 2:].float()
     c, s = cos[None, :, None, :], sin[None, :, None, :]
@@ -82,7 +108,7 @@ def rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
 
 def swiglu(gu: torch.Tensor) -> torch.Tensor:
     """Phi-3 MLP: gate, up = chunk(gate_up, 2); up * silu(gate)."""
-    if BACKEND["swiglu"] == "hip" and gu.is_cuda:
+    if BACKEND["swiglu"] == "hip" and gu.is_cuda and gu.dtype in (torch.bfloat16, torch.float16) and gu.shape[-1] % 16 == 0:
         return _hip.swiglu(gu)
     g, u = gu.chunk(2, dim=-1)
     return (u.float() * F.silu(g.float())).to(gu.dtype)

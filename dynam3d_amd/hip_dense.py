@@ -1,0 +1,121 @@
+"""ctypes wrappers of the hand-written dense kernels (csrc/gemm_kernels.hip, dense_kernels.hip, attn_kernels.hip)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import f32, i32, i64, vp
+
+EPI = dict(none=0, bias=1, bias_quick_gelu=2, bias_gelu=3, res=4, bias_res=5, swiglu=6)
+
+_lib.register("d3d_gemm_nt", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, vp])
+_lib.register("d3d_norm", [vp, vp, vp, vp, i32, i32, i64, i64, f32, i32, i32, vp])
+_lib.register("d3d_rope_inplace", [vp, vp, vp, i32, i32, i32, i32, i64, i32, vp])
+_lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
+_lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def interleave_gate_up(w: torch.Tensor, block: int = 16) -> torch.Tensor:
+    """[gate(I); up(I)] rows -> [g16|u16|g16|u16|...] so one wave's MFMA tiles 2j / 2j+1 hold matching
+    gate / up columns and SwiGLU is applied on accumulator registers (gemm_kernels.hip EPI_SWIGLU)."""
+    I = w.shape[0] // 2
+    g, u = w[:I].view(I // block, block, -1), w[I:].view(I // block, block, -1)
+    return torch.stack([g, u], dim=1).reshape(2 * I, -1).contiguous()
+
+
+class HipDense:
+    PRIMS = {"linear", "layer_norm", "rms_norm", "rope", "swiglu", "resize_normalize"}
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    def has(self, name):
+        return name in self.PRIMS
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def gemm_ok(x, w):
+        K = x.shape[-1]
+        return (w.shape[0] % 128 == 0 and K % 64 == 0 and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16)
+                and x.stride(-1) == 1 and w.is_contiguous())
+
+    def gemm(self, x, w, bias, residual, epi: str):
+        M, K = x.shape
+        N = w.shape[0]
+        n_out = N // 2 if epi == "swiglu" else N
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+        if bias is not None and bias.dtype != x.dtype:
+            bias = bias.to(x.dtype)
+        _lib.check(self.lib.d3d_gemm_nt(_p(x), _p(w), _p(out), _p(bias), _p(residual), M, N, K, x.stride(0), w.stride(0), n_out,
+                                        0 if x.dtype == torch.bfloat16 else 1, EPI[epi], self._stream()))
+        return out
+
+    def linear(self, x, w, b, act, residual=None):
+        x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
+        if x2.stride(-1) != 1 or (x2.stride(0) % 8) != 0:
+            x2 = x2.contiguous()
+        if residual is not None:
+            residual = residual.reshape(-1, w.shape[0])
+            if not residual.is_contiguous():
+                residual = residual.contiguous()
+        if act is None:
+            epi = ("bias_res" if b is not None else "res") if residual is not None else ("bias" if b is not None else "none")
+        else:
+            assert residual is None and b is not None
+            epi = {"quick_gelu": "bias_quick_gelu", "gelu": "bias_gelu"}[act]
+        return self.gemm(x2, w, b, residual, epi)
+
+    def linear_swiglu(self, x, w_interleaved):
+        return self.gemm(x, w_interleaved, None, None, "swiglu")
+
+    # ---- row kernels (csrc/dense_kernels.hip) -------------------------------------------------------------
+    @staticmethod
+    def norm_ok(x):
+        D = x.shape[-1]
+        return x.dtype in (torch.bfloat16, torch.float16) and D % 8 == 0 and D <= 4096 and ((D + 511) // 512) in (1, 2, 3, 4, 6, 8)
+
+    def _norm(self, x, w, b, eps, rms):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(-1) != 1 or x2.stride(0) % 8:
+            x2 = x2.contiguous()
+        y = torch.empty((x2.shape[0], x2.shape[1]), dtype=x.dtype, device=x.device)
+        _lib.check(self.lib.d3d_norm(_p(x2), _p(w), _p(b), _p(y), x2.shape[0], x2.shape[1], x2.stride(0), y.stride(0), eps, 1 if rms else 0,
+                                     0 if x.dtype == torch.bfloat16 else 1, self._stream()))
+        return y.view(x.shape)
+
+    def layer_norm(self, x, w, b, eps):
+        return self._norm(x, w, b, eps, False)
+
+    def rms_norm(self, x, w, eps):
+        return self._norm(x, w, None, eps, True)
+
+    def rope_inplace(self, qkv2d, cos, sin, S, n_rot_heads, hd):
+        """qkv2d (rows, >= n_rot_heads*hd) bf16/fp16, rotated in place; position = row % S."""
+        _lib.check(self.lib.d3d_rope_inplace(_p(qkv2d), _p(cos), _p(sin), qkv2d.shape[0], S, n_rot_heads, hd, qkv2d.stride(0),
+                                             0 if qkv2d.dtype == torch.bfloat16 else 1, self._stream()))
+
+    def resize_normalize(self, rgb_u8, size, mean, std):
+        import numpy as np
+        rgb = rgb_u8.contiguous()
+        B, H, W, _ = rgb.shape
+        out = torch.empty((B, 3, size, size), dtype=torch.float32, device=rgb.device)
+        m, s = np.asarray(mean, np.float32), np.asarray(std, np.float32)
+        _lib.check(self.lib.d3d_resize_normalize(_p(rgb), _p(out), B, H, W, size, m.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), self._stream()))
+        return out
+
+    def swiglu(self, gu):
+        gu2 = gu.reshape(-1, gu.shape[-1]).contiguous()
+        I = gu2.shape[1] // 2
+        out = torch.empty((gu2.shape[0], I), dtype=gu.dtype, device=gu.device)
+        _lib.check(self.lib.d3d_swiglu(_p(gu2), _p(out), gu2.shape[0], I, 0 if gu.dtype == torch.bfloat16 else 1, self._stream()))
+        return out

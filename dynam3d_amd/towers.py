@@ -147,10 +147,10 @@ class _VitTrunk:
             h = D.layer_norm(x, blk["ln1_w"], blk["ln1_b"], 1e-5)
             qkv = D.linear(h.view(B * L, W), blk["qkv_w"], blk["qkv_b"]).view(B, L, 3, c.heads, W // c.heads)
             a = D.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal=False)         # (B,L,H,hd)
-            x = x + D.linear(a.reshape(B * L, W), blk["out_w"], blk["out_b"]).view(B, L, W)
+            x = D.linear(a.reshape(B * L, W), blk["out_w"], blk["out_b"], residual=x.view(B * L, W)).view(B, L, W)
             h = D.layer_norm(x, blk["ln2_w"], blk["ln2_b"], 1e-5)
             h = D.linear(h.view(B * L, W), blk["fc1_w"], blk["fc1_b"], act="quick_gelu")
-            x = x + D.linear(h, blk["fc2_w"], blk["fc2_b"]).view(B, L, W)
+            x = D.linear(h, blk["fc2_w"], blk["fc2_b"], residual=x.view(B * L, W)).view(B, L, W)
         return x
 
 
@@ -227,11 +227,17 @@ class Phi3Decoder:
         f = lambda x: x.detach().to(self.device, torch.float32).contiguous()
         m = "language_model.model"
         self.embed_w = t(sd[m + ".embed_tokens.weight"])
+        # gate/up rows interleaved per 16 for the fused SwiGLU GEMM epilogue (only when the HIP GEMM is active)
+        self.interleave_gu = D.BACKEND["linear"] == "hip" and cfg.mlp % 16 == 0
         self.layers = []
         for i in range(cfg.layers):
             p = f"{m}.layers.{i}"
+            gu = t(sd[p + ".mlp.gate_up_proj.weight"])
+            if self.interleave_gu:
+                from .hip_dense import interleave_gate_up
+                gu = interleave_gate_up(gu)
             self.layers.append(dict(qkv_w=t(sd[p + ".self_attn.qkv_proj.weight"]), o_w=t(sd[p + ".self_attn.o_proj.weight"]),
-                                    gu_w=t(sd[p + ".mlp.gate_up_proj.weight"]), down_w=t(sd[p + ".mlp.down_proj.weight"]),
+                                    gu_w=gu, down_w=t(sd[p + ".mlp.down_proj.weight"]),
                                     n1=f(sd[p + ".input_layernorm.weight"]), n2=f(sd[p + ".post_attention_layernorm.weight"])))
         self.norm_w = f(sd[m + ".norm.weight"])
         self.lm_head_w = t(sd["language_model.lm_head.weight"])
@@ -259,14 +265,14 @@ class Phi3Decoder:
         for L in self.layers:
             h = D.rms_norm(x, L["n1"], c.rms_eps)
             qkv = D.linear(h.view(B * S, Hd), L["qkv_w"], None).view(B, S, c.heads + 2 * c.kv_heads, c.head_dim)
+            qkv = D.rope_qk_(qkv, c.heads + c.kv_heads, cos, sin)
             q, k, v = qkv[:, :, :c.heads], qkv[:, :, c.heads:c.heads + c.kv_heads], qkv[:, :, c.heads + c.kv_heads:]
-            q, k = D.rope(q, cos, sin), D.rope(k, cos, sin)
             a = D.attention(q, k, v, causal=True)
-            x = x + D.linear(a.reshape(B * S, c.heads * c.head_dim), L["o_w"], None).view(B, S, Hd)
+            x = D.linear(a.reshape(B * S, c.heads * c.head_dim), L["o_w"], None, residual=x.view(B * S, Hd)).view(B, S, Hd)
             h = D.rms_norm(x, L["n2"], c.rms_eps)
             with TIMER.range("phi3.gate_up_proj"):
-                gu = D.linear(h.view(B * S, Hd), L["gu_w"], None)
-            x = x + D.linear(D.swiglu(gu), L["down_w"], None).view(B, S, Hd)
+                act = D.linear_swiglu(h.view(B * S, Hd), L["gu_w"], self.interleave_gu)
+            x = D.linear(act, L["down_w"], None, residual=x.view(B * S, Hd)).view(B, S, Hd)
         last = x[torch.arange(B, device=x.device), (lengths.to(x.device).long() - 1)]
         last = D.rms_norm(last, self.norm_w, c.rms_eps)
         return D.linear(last, self.lm_head_w, None).float()

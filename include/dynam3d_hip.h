@@ -158,6 +158,28 @@ int32_t d3d_agent_frame_compact(const float* pool_pos_d, const float* pool_fts_d
                                 int32_t* count_d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Dense kernels for the ViT / Phi-3 towers (a3, a15, a17).  dtype: 0 = bf16, 1 = fp16 (16-bit storage,
+ * fp32 accumulation / statistics).
+ * ---------------------------------------------------------------------------------------------- */
+/* C = epilogue(A[M,K] W[N,K]^T): nn.Linear layout.  epilogue: 0 none, 1 +bias, 2 +bias QuickGELU (clip/model.py:162),
+ * 3 +bias GELU, 4 +residual, 5 +bias +residual, 6 SwiGLU over per-16 interleaved gate/up rows of W (writes N/2 cols).
+ * Needs N % 128 == 0, K % 64 == 0, lda/ldw % 8 == 0. */
+int32_t d3d_gemm_nt(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
+                    int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
+                    void* stream);
+/* LayerNorm (rms = 0; clip/model.py:153-159: float32 statistics) or RMSNorm (rms = 1; Phi-3) over rows of D <= 4096 */
+int32_t d3d_norm(const void* x_d, const float* w_d, const float* b_d, void* y_d, int32_t rows, int32_t D, int64_t ldx,
+                 int64_t ldy, float eps, int32_t rms, int32_t dtype, void* stream);
+/* in-place half-split rotary embedding on the first n_rot_heads heads of each fused-QKV row; position = row % S */
+int32_t d3d_rope_inplace(void* qkv_d, const float* cos_d, const float* sin_d, int32_t rows, int32_t S, int32_t n_rot_heads,
+                         int32_t head_dim, int64_t ld, int32_t dtype, void* stream);
+/* out[m,i] = up * silu(gate) for a plain [gate(I) | up(I)] projection output */
+int32_t d3d_swiglu(const void* gate_up_d, void* out_d, int64_t rows, int32_t I, int32_t dtype, void* stream);
+/* a3 front-end (resnet_encoders.py:267-271): uint8 HWC -> bicubic SxS (rounded back to uint8) -> /255 -> normalise, f32 CHW */
+int32_t d3d_resize_normalize(const uint8_t* rgb_d, float* out_d, int32_t B, int32_t H, int32_t W, int32_t S,
+                             const float* mean3_h, const float* std3_h, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host-side bookkeeping (ids / dict semantics of VLN-FF:357-393, 433-475, 623-691, 694-756).
  * Integer-only control plane; all float work stays in the kernels above.  Not thread-safe per
  * handle.  compat: 0 = 'reference' (quirks F11/Z1 reproduced), 1 = 'fixed' (id == row).

@@ -1,0 +1,87 @@
+"""GPU: hand-written dense kernels (GEMM + fused epilogues, LayerNorm/RMSNorm, RoPE, SwiGLU, bicubic front-end)
+against plain PyTorch float32 references of the same op.  Tolerances: outputs are bf16/fp16, i.e. one final
+rounding (unit roundoff 3.9e-3 / 4.9e-4) on top of fp32 accumulation -> relative L2 <= 3e-3 (bf16) / 6e-4 (fp16)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hd():
+    from dynam3d_amd.hip_dense import HipDense
+    return HipDense()
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
+def test_gemm_epilogues_asymmetric(hd, dt, tol):
+    from dynam3d_amd.hip_dense import interleave_gate_up
+    torch.manual_seed(1)
+    for M, N, K in ((300, 256, 192), (1000, 384, 1024), (77, 128, 64), (513, 1024, 3072)):
+        x = (torch.randn(M, K, device="cuda") * 0.7).to(dt)
+        w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
+        w[3] *= 4.0                                   # asymmetric operands: transposes cannot cancel
+        x[:, 5] += 1.0
+        b = (torch.randn(N, device="cuda") * 0.3).to(dt)
+        r = torch.randn(M, N, device="cuda").to(dt)
+        y32 = x.float() @ w.float().t()
+        cases = {
+            "none": (hd.linear(x, w, None, None), y32),
+            "bias": (hd.linear(x, w, b, None), y32 + b.float()),
+            "qgelu": (hd.linear(x, w, b, "quick_gelu"), (lambda t: t * torch.sigmoid(1.702 * t))(y32 + b.float())),
+            "gelu": (hd.linear(x, w, b, "gelu"), F.gelu(y32 + b.float())),
+            "res": (hd.linear(x, w, None, None, r), y32 + r.float()),
+            "bias_res": (hd.linear(x, w, b, None, r), y32 + b.float() + r.float()),
+            "swiglu": (hd.linear_swiglu(x, interleave_gate_up(w)), y32[:, N // 2:] * F.silu(y32[:, :N // 2])),
+        }
+        for name, (got, exp) in cases.items():
+            assert got.dtype == dt and got.shape == exp.shape
+            assert rel(got.float(), exp) < tol, (name, M, N, K, rel(got.float(), exp))
+        # strided A (a column slice of a wider buffer)
+        big = (torch.randn(M, K + 64, device="cuda")).to(dt)
+        assert rel(hd.linear(big[:, :K], w, None, None).float(), big[:, :K].float() @ w.float().t()) < tol
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
+def test_norms_rope_swiglu(hd, dt, tol):
+    torch.manual_seed(2)
+    for D in (768, 1024, 3072, 4096, 128):
+        x = (torch.randn(1001, D, device="cuda") * 2 + 0.3).to(dt)
+        w, b = torch.randn(D, device="cuda") * 0.2 + 1, torch.randn(D, device="cuda") * 0.1
+        assert rel(hd.layer_norm(x, w, b, 1e-5).float(), F.layer_norm(x.float(), (D,), w, b, 1e-5)) < tol
+        xf = x.float()
+        assert rel(hd.rms_norm(x, w, 1e-5).float(), xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * w) < tol
+    B, S, H, hdm = 3, 50, 6, 96
+    qkv = torch.randn(B, S, 3 * H, hdm, device="cuda").to(dt)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hdm, 2, device="cuda").float() / hdm))
+    ang = torch.arange(S, device="cuda").float()[:, None] * inv[None]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    ref = qkv.clone().float()
+    x1, x2 = ref[:, :, :2 * H, :hdm // 2].clone(), ref[:, :, :2 * H, hdm // 2:].clone()
+    c, s = cos[None, :, None], sin[None, :, None]
+    ref[:, :, :2 * H] = torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], -1)
+    got = qkv.clone()
+    hd.rope_inplace(got.view(B * S, -1), cos, sin, S, 2 * H, hdm)
+    assert rel(got.float(), ref) < tol and torch.equal(got[:, :, 2 * H:], qkv[:, :, 2 * H:])
+    gu = torch.randn(333, 2 * 8192, device="cuda").to(dt)
+    assert rel(hd.swiglu(gu).float(), gu[:, 8192:].float() * F.silu(gu[:, :8192].float())) < tol
+
+
+def test_resize_normalize_matches_torch_bicubic(hd):
+    from dynam3d_amd import dense_ops as D
+    from dynam3d_amd.towers import CLIP_MEAN, CLIP_STD
+    rng = np.random.default_rng(4)
+    for hw in (224, 336, 97):
+        rgb = torch.from_numpy(rng.integers(0, 256, (3, hw, hw, 3), dtype=np.uint8)).cuda()
+        got = hd.resize_normalize(rgb, 336, CLIP_MEAN, CLIP_STD)
+        exp = D.resize_normalize(rgb.cpu(), 336, CLIP_MEAN, CLIP_STD).cuda()      # torch CPU bicubic (the oracle's op)
+        # identical except where the float32 interpolant sits within rounding noise of a .5 boundary: <= 1 LSB (1/255/std)
+        diff = (got - exp).abs()
+        assert float(diff.max()) <= 1.0 / 255 / min(CLIP_STD) + 1e-5
+        assert float((diff > 1e-5).float().mean()) < 2e-3
