@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--warm-steps", type=int, default=8, help="untimed trajectory steps before warmup (warm memory)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "on", "off"])
-    ap.add_argument("--hip-dense", default="layer_norm,rms_norm,rope,swiglu,resize_normalize",
+    ap.add_argument("--hip-dense", default="all",
                     help="comma list of dense primitives on hand-written HIP kernels (linear,layer_norm,rms_norm,rope,swiglu,resize_normalize), 'all' or 'none'")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()

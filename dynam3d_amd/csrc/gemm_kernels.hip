@@ -73,21 +73,92 @@ __device__ __forceinline__ float act_qgelu(float x) { return x / (1.0f + __expf(
 __device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
 
-// One 128x64 operand tile -> LDS (lane-linear image, source-side swizzle).  `rows_valid` clamps the
-// row index (edge tiles re-read the last valid row; their outputs are never stored).
-__device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ g, int64_t ld, int row0, int rows_valid, int k0,
-                                           uint16_t* lds_tile, int wave, int lane) {
-    // 16 KiB tile = 16 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces w, w+4, w+8, w+12
+// Operand tile (ROWS x 64, 16-bit) -> LDS by LDS-DMA (global_load_lds_dwordx4: 16 B per lane, 1 KiB per wave
+// instruction = 8 rows x 128 B, no VGPR round trip).  The image is lane-linear, so the ds_read bank-conflict
+// swizzle is applied to the per-lane SOURCE chunk (chunk ^= row & 7) and undone in the read address.
+// `rows_valid` clamps the row index: edge tiles re-read the last valid row (their outputs are never stored).
+//
+// Issued from inline asm on purpose: hipcc counts a builtin LDS-DMA as a pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read of ANY buffer, which serialises prefetch and compute.
+// In asm the DMA is invisible to that bookkeeping; the kernels below wait for it explicitly (counted in tiles)
+// and order it against the ds_reads with s_barrier.  M0 (LDS destination base) is saved/restored around the
+// statement (cdna_hip_programming.md 5.7).
+template <int WAVES>
+__device__ __forceinline__ void stage_tile_dma(const uint16_t* __restrict__ g, int64_t ld, int row0, int rows_valid, int k0,
+                                               uint32_t lds_byte_addr, int wave, int lane) {
+    // wave w issues pieces w, w+WAVES, w+2*WAVES, w+3*WAVES  (4*WAVES pieces of 8 rows = 32*WAVES rows)
+    const uint16_t* src[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const int piece = wave + p * 4;
-        const int r = piece * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (r & 7);                 // swizzled source chunk for LDS chunk (lane&7)
+        const int r = (wave + p * WAVES) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (r & 7);
         int gr = row0 + r;
         gr = gr < rows_valid ? gr : rows_valid - 1;
-        const uint16_t* src = g + (int64_t)gr * ld + k0 + c * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds_tile + piece * 512), 16, 0, 0);
+        src[p] = g + (int64_t)gr * ld + k0 + c * 8;
+    }
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr + (uint32_t)wave * 1024u);
+    uint32_t keep;
+    constexpr int STEP = WAVES * 1024;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_add_u32 m0, m0, %6\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_add_u32 m0, m0, %6\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, off\n\t"
+        "s_add_u32 m0, m0, %6\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(dst), "i"(STEP)
+        : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+// Epilogue for one 16-column MFMA tile of one output row: this lane owns columns n16 + fg*4 .. +3.
+// SWIGLU: `a` is the gate tile, `b` the matching up tile (weights interleaved per 16 rows); output column n16/2.
+template <bool BF16, int EPI>
+__device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
+                                       const uint16_t* __restrict__ residual, int m, int n16, int fg, int64_t ldc) {
+    uint16_t o[4];
+    if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = from_f32<BF16>(b[r] * act_silu(a[r]));
+        *reinterpret_cast<uint2*>(C + (int64_t)m * ldc + n16 / 2 + fg * 4) = *reinterpret_cast<const uint2*>(o);
+    } else {
+        const int n = n16 + fg * 4;
+        float v[4] = {a[0], a[1], a[2], a[3]};
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES) {
+            const uint2 bb = *reinterpret_cast<const uint2*>(bias + n);
+            const uint16_t* bp = reinterpret_cast<const uint16_t*>(&bb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += to_f32<BF16>(bp[r]);
+        }
+        if constexpr (EPI == EPI_BIAS_QGELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_qgelu(v[r]);
+        }
+        if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_gelu(v[r]);
+        }
+        if constexpr (EPI == EPI_RES || EPI == EPI_BIAS_RES) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(residual + (int64_t)m * ldc + n);
+            const uint16_t* rp = reinterpret_cast<const uint16_t*>(&rr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += to_f32<BF16>(rp[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = from_f32<BF16>(v[r]);
+        *reinterpret_cast<uint2*>(C + (int64_t)m * ldc + n) = *reinterpret_cast<const uint2*>(o);
     }
 }
 
@@ -123,8 +194,9 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
 
     const int nk = K / BK;
     // LDS: buffer b -> A tile at smem + b*2*BM*BK, B tile right behind it
-    stage_tile(A, lda, row0, M, 0, smem, wave, lane);
-    stage_tile(W, ldw, col0, N, 0, smem + BM * BK, wave, lane);
+    const uint32_t lds0 = lds_addr_of(smem);
+    stage_tile_dma<4>(A, lda, row0, M, 0, lds0, wave, lane);
+    stage_tile_dma<4>(W, ldw, col0, N, 0, lds0 + BM * BK * 2, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -132,9 +204,9 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) {
-            uint16_t* nxt = smem + (cur ^ 1) * (2 * BM * BK);
-            stage_tile(A, lda, row0, M, (t + 1) * BK, nxt, wave, lane);
-            stage_tile(W, ldw, col0, N, (t + 1) * BK, nxt + BM * BK, wave, lane);
+            const uint32_t nxt = lds0 + (cur ^ 1) * (2 * BM * BK * 2);
+            stage_tile_dma<4>(A, lda, row0, M, (t + 1) * BK, nxt, wave, lane);
+            stage_tile_dma<4>(W, ldw, col0, N, (t + 1) * BK, nxt + BM * BK * 2, wave, lane);
         }
         const uint16_t* la = smem + cur * (2 * BM * BK);
         const uint16_t* lb = la + BM * BK;
@@ -153,8 +225,8 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<BF16>(bf[j], af[i], acc[i][j]);   // D = C^T tile: rows n, cols m
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
     // ---- epilogue: lane holds, for tile (i,j): row m = row0+wr*64+i*16+fi, cols n = col0+wc*64+j*16+fg*4 .. +3
@@ -163,50 +235,148 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
         const int m = row0 + wr * 64 + i * 16 + fi;
         if (m >= M) continue;
         if constexpr (EPI == EPI_SWIGLU) {
-            // columns interleaved per 64: [gate 64 | up 64] inside every 128-wide tile; wc==0 waves hold gate, wc==1 up.
-            // exchange through LDS is avoided by pairing tiles j of the two wave columns via __shfl is not possible
-            // (different waves) -> the host lays gate/up out per 16: [g16|u16|g16|u16...], so tiles j=0,2 are gate and
-            // j=1,3 the matching up columns of the SAME wave.
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                const int n_out = (col0 + wc * 64 + j * 16) / 2 + fg * 4;
-                uint16_t o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = from_f32<BF16>(acc[i][j + 1][r] * act_silu(acc[i][j][r]));
-                *reinterpret_cast<uint2*>(C + (int64_t)m * ldc + n_out) = *reinterpret_cast<const uint2*>(o);
-            }
+            for (int j = 0; j < 4; j += 2) store4<BF16, EPI>(acc[i][j], acc[i][j + 1], C, bias, residual, m, col0 + wc * 64 + j * 16, fg, ldc);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = col0 + wc * 64 + j * 16 + fg * 4;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QGELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES) {
-                    const uint2 bb = *reinterpret_cast<const uint2*>(bias + n);
-                    const uint16_t* bp = reinterpret_cast<const uint16_t*>(&bb);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += to_f32<BF16>(bp[r]);
-                }
-                if constexpr (EPI == EPI_BIAS_QGELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_qgelu(v[r]);
-                }
-                if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_gelu(v[r]);
-                }
-                if constexpr (EPI == EPI_RES || EPI == EPI_BIAS_RES) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(residual + (int64_t)m * ldc + n);
-                    const uint16_t* rp = reinterpret_cast<const uint16_t*>(&rr);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += to_f32<BF16>(rp[r]);
-                }
-                uint16_t o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = from_f32<BF16>(v[r]);
-                *reinterpret_cast<uint2*>(C + (int64_t)m * ldc + n) = *reinterpret_cast<const uint2*>(o);
-            }
+            for (int j = 0; j < 4; ++j) store4<BF16, EPI>(acc[i][j], acc[i][j], C, bias, residual, m, col0 + wc * 64 + j * 16, fg, ldc);
         }
     }
+}
+
+// ================================================================================================
+// 256 x 256 x 64 tile, 8 waves (512 threads, one workgroup per CU), two wave GROUPS running half a
+// K-tile apart so that on every SIMD one wave streams fragments LDS -> registers (and the whole
+// workgroup's next tile HBM -> LDS) while its partner wave issues MFMAs back to back:
+//
+//     step k   : group 0: LOAD(half k)        group 1: COMPUTE(half k-1)      raw barrier
+//     step k+1 : group 0: COMPUTE(half k)     group 1: LOAD(half k)           raw barrier
+//
+// A step handles one K-half (32 deep) of the wave's 128 x 64 sub-tile: LOAD = 12 conflict-free ds_read_b128
+// (8 A + 4 B fragments, 48 VGPRs), COMPUTE = 32 x v_mfma_f32_16x16x32 from registers under s_setprio(1); four
+// steps per 64-deep K-tile.  The LDS-DMA of tile t+1 is issued at the START of tile t's first step and only
+// waited for at the END of its fourth (four MFMA phases in flight); raw s_barrier (not __syncthreads) keeps
+// hipcc from draining it early.  Two 64 KiB LDS buffers (128 KiB), 128 accumulator VGPRs per wave.
+// ================================================================================================
+constexpr int TM = 256, TN = 256, T_THREADS = 512;
+
+template <bool BF16, int EPI>
+__global__ void __launch_bounds__(T_THREADS, 2)
+k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* __restrict__ C,
+              const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, int M, int N, int K, int64_t lda,
+              int64_t ldw, int64_t ldc, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2][A 256x64 | B 256x64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = tiles_m * tiles_n;
+    int wg = blockIdx.x;
+    {
+        const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    constexpr int GM = 4;
+    const int group = wg / (GM * tiles_n);
+    const int gm0 = group * GM;
+    const int gsz = min(GM, tiles_m - gm0);
+    const int tm = gm0 + (wg % (GM * tiles_n)) % gsz;
+    const int tn = (wg % (GM * tiles_n)) / gsz;
+    const int row0 = tm * TM, col0 = tn * TN;
+
+    const int grp = wave >> 2;                 // wave group == M half of the tile; waves w and w+4 share a SIMD
+    const int wn = wave & 3;
+    const int fi = lane & 15, fg = lane >> 4;
+    constexpr int BUF = 2 * TM * BK;           // elements per K-tile buffer (A then B)
+
+    float4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+    uint4 af[8], bf[4];
+
+    // LOAD(t, kk): the 12 fragments of K-half kk (32 deep) of tile t -> 48 VGPRs
+    auto LOAD = [&](int t, int kk) {
+        const uint16_t* la = smem + (t & 1) * BUF;
+        const uint16_t* lb = la + TM * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rb = wn * 64 + j * 16 + fi;
+            bf[j] = *reinterpret_cast<const uint4*>(lb + rb * BK + (((kk * 4 + fg) ^ (rb & 7)) << 3));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ra = grp * 128 + i * 16 + fi;
+            af[i] = *reinterpret_cast<const uint4*>(la + ra * BK + (((kk * 4 + fg) ^ (ra & 7)) << 3));
+        }
+    };
+    auto COMPUTE = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<BF16>(bf[j], af[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int nk = K / BK;
+    const uint32_t lds0 = lds_addr_of(smem);
+    stage_tile_dma<8>(A, lda, row0, M, 0, lds0, wave, lane);
+    stage_tile_dma<8>(W, ldw, col0, N, 0, lds0 + TM * BK * 2, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ONE instruction stream for both groups: LOAD(half) | barrier | COMPUTE | barrier ...; group 1 executes one
+    // extra barrier up front, so it always runs exactly one step behind group 0 (and group 0 one extra at the
+    // end).  Tile t+1 goes in flight at the start of tile t and must have landed one step before group 0 reads it:
+    // group 0 drains its share at the end of its 4th step, group 1 (a step late) at the end of its 3rd.
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) {
+            const uint32_t nxt = lds0 + ((t + 1) & 1) * (BUF * 2);
+            stage_tile_dma<8>(A, lda, row0, M, (t + 1) * BK, nxt, wave, lane);
+            stage_tile_dma<8>(W, ldw, col0, N, (t + 1) * BK, nxt + TM * BK * 2, wave, lane);
+        }
+        LOAD(t, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        COMPUTE();
+        __builtin_amdgcn_s_barrier();
+        LOAD(t, 1);
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        COMPUTE();
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = row0 + grp * 128 + i * 16 + fi;
+        if (m >= M) continue;
+        if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) store4<BF16, EPI>(acc[i][j], acc[i][j + 1], C, bias, residual, m, col0 + wn * 64 + j * 16, fg, ldc);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) store4<BF16, EPI>(acc[i][j], acc[i][j], C, bias, residual, m, col0 + wn * 64 + j * 16, fg, ldc);
+        }
+    }
+}
+
+template <bool BF16, int EPI>
+int32_t launch256(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
+                  int64_t ldw, int64_t ldc, hipStream_t s) {
+    const int tm = (M + TM - 1) / TM, tn = N / TN;
+    const size_t sh = 2 * 2 * TM * BK * sizeof(uint16_t);   // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
+                       (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn);
+    D3D_LAUNCH_CHECK();
 }
 
 template <bool BF16, int EPI>
@@ -230,9 +400,34 @@ extern "C" {
 
 // C[M,N] (or [M,N/2] for SwiGLU) = epi(A[M,K] W[N,K]^T).  dtype: 0 = bf16, 1 = fp16.  Requires N % 128 == 0, K % 64 == 0,
 // 16-byte aligned rows (lda, ldw multiples of 8).  M is arbitrary (edge tiles are masked).
+int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
+                         int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream);
+
 int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
                     int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, void* stream) {
+    // Tile choice.  The 256x256 staggered kernel runs one workgroup per CU, so it pays when its grid covers the 256 CUs
+    // for several rounds; its M remainder (M % 256 rows) goes to the 128x128 kernel instead of a mostly-empty row of
+    // 256-tiles (at M = 7200 that turns 29 x N/256 workgroups = 7.25 rounds into 28 x N/256 = exactly 7 for N = 16384).
+    const int64_t rows256 = (int64_t)(M / TM) * TM;
+    const int64_t blocks256 = (rows256 / TM) * (N / TN);
+    if (N % TN == 0 && blocks256 >= 768) {
+        int32_t rc = d3d_gemm_nt_tile(A, W, C, bias, residual, (int32_t)rows256, N, K, lda, ldw, ldc, dtype, epilogue, 256, stream);
+        if (rc != D3D_OK || rows256 == M) return rc;
+        const char* a8 = (const char*)A + rows256 * lda * 2;
+        char* c8 = (char*)C + rows256 * ldc * 2;
+        const char* r8 = residual ? (const char*)residual + rows256 * ldc * 2 : nullptr;
+        return d3d_gemm_nt_tile(a8, W, c8, bias, r8, (int32_t)(M - rows256), N, K, lda, ldw, ldc, dtype, epilogue, 128, stream);
+    }
+    return d3d_gemm_nt_tile(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, dtype, epilogue, 128, stream);
+}
+
+int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
+                         int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream) {
     if (M <= 0) return D3D_OK;
+    if (tile == 256 && N % TN != 0) {
+        d3d_set_error_("d3d_gemm_nt_tile: tile 256 needs N % 256 == 0");
+        return D3D_EINVAL;
+    }
     if (N % BN != 0 || K % BK != 0 || (lda & 7) || (ldw & 7) || (ldc & 3)) {
         d3d_set_error_("d3d_gemm_nt: need N % 128 == 0, K % 64 == 0, lda/ldw % 8 == 0, ldc % 4 == 0");
         return D3D_EINVAL;
@@ -240,6 +435,9 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
     hipStream_t s = (hipStream_t)stream;
 #define D3D_GEMM_CASE(E)                                                                                              \
     case E:                                                                                                           \
+        if (tile == 256)                                                                                              \
+            return dtype == 0 ? launch256<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)                 \
+                              : launch256<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);               \
         return dtype == 0 ? launch<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)                        \
                           : launch<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);
     switch (epilogue) {

@@ -12,6 +12,7 @@ from ._lib import f32, i32, i64, vp
 EPI = dict(none=0, bias=1, bias_quick_gelu=2, bias_gelu=3, res=4, bias_res=5, swiglu=6)
 
 _lib.register("d3d_gemm_nt", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, vp])
+_lib.register("d3d_gemm_nt_tile", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32, vp])
 _lib.register("d3d_norm", [vp, vp, vp, vp, i32, i32, i64, i64, f32, i32, i32, vp])
 _lib.register("d3d_rope_inplace", [vp, vp, vp, i32, i32, i32, i32, i64, i32, vp])
 _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
@@ -49,6 +50,8 @@ class HipDense:
         return (w.shape[0] % 128 == 0 and K % 64 == 0 and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16)
                 and x.stride(-1) == 1 and w.is_contiguous())
 
+    TILE = 0   # 0 = library heuristic, 128 / 256 = force a tile (benchmarking)
+
     def gemm(self, x, w, bias, residual, epi: str):
         M, K = x.shape
         N = w.shape[0]
@@ -56,8 +59,14 @@ class HipDense:
         out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
         if bias is not None and bias.dtype != x.dtype:
             bias = bias.to(x.dtype)
-        _lib.check(self.lib.d3d_gemm_nt(_p(x), _p(w), _p(out), _p(bias), _p(residual), M, N, K, x.stride(0), w.stride(0), n_out,
-                                        0 if x.dtype == torch.bfloat16 else 1, EPI[epi], self._stream()))
+        dt = 0 if x.dtype == torch.bfloat16 else 1
+        if self.TILE:
+            tile = self.TILE if (self.TILE == 128 or N % 256 == 0) else 128
+            _lib.check(self.lib.d3d_gemm_nt_tile(_p(x), _p(w), _p(out), _p(bias), _p(residual), M, N, K, x.stride(0), w.stride(0), n_out,
+                                                 dt, EPI[epi], tile, self._stream()))
+        else:
+            _lib.check(self.lib.d3d_gemm_nt(_p(x), _p(w), _p(out), _p(bias), _p(residual), M, N, K, x.stride(0), w.stride(0), n_out,
+                                            dt, EPI[epi], self._stream()))
         return out
 
     def linear(self, x, w, b, act, residual=None):

@@ -48,11 +48,18 @@ for dt in (torch.bfloat16, torch.float16):
         elif epi == "bias_quick_gelu":
             ref = lambda: (lambda y: y * torch.sigmoid(1.702 * y))(F.linear(x, w, b))
             own = lambda: hd.linear(x, w, b, "quick_gelu")
-        yo, yr = own().float(), ref().float()
-        ref64 = None
-        err = (yo - yr).norm() / yr.norm()
-        t_own, t_ref, t_plain = timeit(own), timeit(ref), timeit(lambda: F.linear(x, w))
+        yr = ref().float()
+        res = {}
+        for tile in (128, 256, 0):
+            if tile == 256 and n % 256:
+                continue
+            HipDense.TILE = tile
+            err = (own().float() - yr).norm() / yr.norm()
+            res[tile] = (timeit(own), float(err))
+        HipDense.TILE = 0
+        t_ref, t_plain = timeit(ref), timeit(lambda: F.linear(x, w))
         fl = 2.0 * m * n * k / 1e9
-        print(f"{str(dt)[6:]:9s} {name:20s} M={m} N={n} K={k} relerr={err:.2e} own {t_own:.3f} ms ({fl / t_own:.0f} TF/s)  torch+epi {t_ref:.3f} ms ({fl / t_ref:.0f})  torch gemm only {t_plain:.3f} ms ({fl / t_plain:.0f})", flush=True)
+        own_s = "  ".join(f"own{t} {v[0]:.3f} ms ({fl / v[0]:.0f} TF/s, err {v[1]:.1e})" for t, v in res.items())
+        print(f"{str(dt)[6:]:9s} {name:20s} M={m} N={n} K={k} {own_s}  torch+epi {t_ref:.3f} ms ({fl / t_ref:.0f})  torch gemm only {t_plain:.3f} ms ({fl / t_plain:.0f})", flush=True)
     if len(sys.argv) > 2:
         break
