@@ -111,18 +111,30 @@ k_norm(const uint16_t* __restrict__ x, const float* __restrict__ w, const float*
 template <bool BF16>
 __global__ void k_rope(uint16_t* __restrict__ qkv, const float* __restrict__ cos_t, const float* __restrict__ sin_t, int rows,
                        int S, int n_rot_heads, int hd, int64_t ld) {
-    const int half = hd >> 1;
-    const int per_row = n_rot_heads * half;
+    // one thread = 8 consecutive rotation pairs of one head: two 16-byte loads / stores (head_dim/2 % 8 == 0)
+    const int half = hd >> 1, cpb = half >> 3;                    // chunks of 8 pairs per head
+    const int per_row = n_rot_heads * cpb;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)rows * per_row) return;
     const int row = (int)(i / per_row), r = (int)(i % per_row);
-    const int h = r / half, p = r % half;
+    const int h = r / cpb, p = (r % cpb) * 8;
     const int pos = row % S;
-    uint16_t* base = qkv + (int64_t)row * ld + h * hd;
-    const float x1 = ld16<BF16>(base[p]), x2 = ld16<BF16>(base[p + half]);
-    const float c = cos_t[pos * half + p], s = sin_t[pos * half + p];
-    base[p] = st16<BF16>(x1 * c - x2 * s);
-    base[p + half] = st16<BF16>(x2 * c + x1 * s);
+    uint16_t* base = qkv + (int64_t)row * ld + h * hd + p;
+    const uint4 a = *reinterpret_cast<const uint4*>(base), b = *reinterpret_cast<const uint4*>(base + half);
+    const uint16_t* ah = reinterpret_cast<const uint16_t*>(&a);
+    const uint16_t* bh = reinterpret_cast<const uint16_t*>(&b);
+    const float4 c0 = *reinterpret_cast<const float4*>(cos_t + pos * half + p), c1 = *reinterpret_cast<const float4*>(cos_t + pos * half + p + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(sin_t + pos * half + p), s1 = *reinterpret_cast<const float4*>(sin_t + pos * half + p + 4);
+    const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    uint16_t o1[8], o2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x1 = ld16<BF16>(ah[j]), x2 = ld16<BF16>(bh[j]);
+        o1[j] = st16<BF16>(x1 * cc[j] - x2 * ss[j]);
+        o2[j] = st16<BF16>(x2 * cc[j] + x1 * ss[j]);
+    }
+    *reinterpret_cast<uint4*>(base) = *reinterpret_cast<const uint4*>(o1);
+    *reinterpret_cast<uint4*>(base + half) = *reinterpret_cast<const uint4*>(o2);
 }
 
 // Bicubic (A = -0.75, align_corners = False, border-clamped taps) resize of uint8 HWC images to SxS, result
@@ -242,7 +254,11 @@ int32_t d3d_norm(const void* x, const float* w, const float* b, void* y, int32_t
 int32_t d3d_rope_inplace(void* qkv, const float* cos_t, const float* sin_t, int32_t rows, int32_t S, int32_t n_rot_heads,
                          int32_t head_dim, int64_t ld, int32_t dtype, void* stream) {
     if (rows <= 0) return D3D_OK;
-    const int64_t n = (int64_t)rows * n_rot_heads * (head_dim / 2);
+    if ((head_dim / 2) % 8 != 0 || (ld & 7)) {
+        d3d_set_error_("d3d_rope_inplace: head_dim/2 and ld must be multiples of 8");
+        return D3D_EINVAL;
+    }
+    const int64_t n = (int64_t)rows * n_rot_heads * (head_dim / 16);
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (dtype == 0)
         hipLaunchKernelGGL(k_rope<true>, grid, block, 0, (hipStream_t)stream, (uint16_t*)qkv, cos_t, sin_t, rows, S, n_rot_heads, head_dim, ld);

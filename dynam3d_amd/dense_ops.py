@@ -92,7 +92,8 @@ def rope_qk_(qkv: torch.Tensor, n_rot_heads: int, cos: torch.Tensor, sin: torch.
     """Rotate the first `n_rot_heads` heads (q heads then k heads) of the fused projection qkv (B,S,Htot,hd);
     in place on the HIP backend (one pass over q,k instead of slice/float/cat round trips)."""
     B, S, Ht, hd = qkv.shape
-    if BACKEND["rope"] == "hip" and qkv.is_cuda and qkv.is_contiguous() and qkv.dtype in (torch.bfloat16, torch.float16):
+    if (BACKEND["rope"] == "hip" and qkv.is_cuda and qkv.is_contiguous() and qkv.dtype in (torch.bfloat16, torch.float16)
+            and (hd // 2) % 8 == 0):
         _hip.rope_inplace(qkv.view(B * S, Ht * hd), cos, sin, S, n_rot_heads, hd)
         return qkv
     return torch.cat([rope(qkv[:, :, :n_rot_heads], cos, sin), qkv[:, :, n_rot_heads:]], dim=2)

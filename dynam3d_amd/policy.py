@@ -117,6 +117,11 @@ class Dynam3D_VLN:
         self.tokenizer = tokenizer or SyntheticTokenizer(cfg.llm.vocab)
         self.last_lengths = None
 
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     # ---- reference surface -----------------------------------------------------------------------------
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
@@ -156,6 +161,16 @@ class Dynam3D_VLN:
         depth24 = self._depth24(depth, V, depth_scale)                                        # (B,V,576) metres
         pixels = preprocess_rgb(rgb)                                                          # shared by both towers
         _, grid = self.rgb_encoder.forward(pixels)                                            # (B*V,576,768) fp16, stays on device
+        # The llava vision tower only needs `pixels`: run it on a second HIP stream underneath the 3D-token
+        # update, whose host round trips (hit lists, merge decisions, Ni/Nz) would otherwise idle the GPU.
+        side = None
+        if self.device.type == "cuda":
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                patch_feat = self.llava_vision.forward(pixels)
+            pixels.record_stream(side)
         if delete_old_features:
             dfull = self.ops.preprocess_depth(depth[..., 0], *depth_scale).view(B, V, depth.shape[1], depth.shape[2])
             ff.delete_old_features_from_camera_frustum(dfull, agent_positions, agent_heading_angles, num_of_views=V)
@@ -171,7 +186,12 @@ class Dynam3D_VLN:
         zfts, zrel = torch.cat(env["batch_zone_fts"]), torch.cat(env["batch_zone_relative_position"])
         inst_tok = self._mlp(torch.cat([ifts, self._mlp(irel, "instance_position_embedding")], -1), "instance_projector")   # VLN-POL:434
         zone_tok = self._mlp(torch.cat([zfts, self._mlp(zrel, "zone_position_embedding")], -1), "zone_projector")           # VLN-POL:435
-        patch_tok = self.llava_vision.forward(pixels).float() + patch_pos                      # VLN-POL:448-453
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            patch_feat.record_stream(torch.cuda.current_stream())
+        else:
+            patch_feat = self.llava_vision.forward(pixels)
+        patch_tok = patch_feat.float() + patch_pos                                             # VLN-POL:448-453
         patch_tok = patch_tok.view(B, V * ff.P, -1)
         # prompt (VLN-POL:436): ids 0..1 are kept in front of the visual prefix, the text follows it
         tok = self.tokenizer

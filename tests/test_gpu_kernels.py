@@ -242,3 +242,16 @@ def test_row_movers_and_agent_frame(ops):
     assert torch.equal(pools2.rows_fts[1, 10:586], grid[0].half()) and torch.equal(pools2.rows_fts[0, 600:1176], grid[1].half())
     ops.append_fts(grid.half(), dev(np.array([0, 1], np.int32)), dev(np.array([0, 600], np.int32)), pools2)
     assert torch.equal(pools2.rows_fts[0, 0:576], grid[0].half())
+
+
+def test_kdtree_api_shim_matches_golden(ops):
+    """`build_kd_tree(points).query(q, nr_nns_searches=k)` -- the torch_kdtree surface the reference calls."""
+    from dynam3d_amd.kdtree import build_kd_tree
+    g = load("g3_knn.npz")
+    for i in range(int(g["n"])):
+        pts = torch.from_numpy(g[f"pts_{i}"]).cuda()
+        tree = build_kd_tree(pts)
+        pts.fill_(0.0)                                          # the tree owns a copy (snapshot semantics)
+        d2, idx = tree.query(torch.from_numpy(g[f"q_{i}"]).cuda(), nr_nns_searches=int(g[f"k_{i}"]))
+        assert idx.dtype == torch.int64 and np.array_equal(idx.cpu().numpy(), g[f"idx_{i}"])
+        assert np.array_equal(bits(d2.cpu().numpy()), bits(g[f"d2_{i}"]))
