@@ -22,6 +22,7 @@ HIP_SOURCES = [
     ("dense_kernels.hip", ["-ffp-contract=fast"]),
     ("gemm_kernels.hip", ["-ffp-contract=fast"]),
     ("attn_kernels.hip", ["-ffp-contract=fast"]),
+    ("render_kernels.hip", ["-ffp-contract=off"]),
 ]
 CPP_SOURCES = ["ff_state.cpp", "d3d_error.cpp"]
 

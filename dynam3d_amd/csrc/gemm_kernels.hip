@@ -36,7 +36,7 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using float4v = __attribute__((ext_vector_type(4))) float;
 
-enum Epi : int { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_QGELU = 2, EPI_BIAS_GELU = 3, EPI_RES = 4, EPI_BIAS_RES = 5, EPI_SWIGLU = 6 };
+enum Epi : int { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_QGELU = 2, EPI_BIAS_GELU = 3, EPI_RES = 4, EPI_BIAS_RES = 5, EPI_SWIGLU = 6, EPI_LRELU = 7 };
 
 template <bool BF16>
 __device__ __forceinline__ float4v mfma16(const uint4& a, const uint4& b, float4v c) {
@@ -149,6 +149,10 @@ __device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint1
         if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_gelu(v[r]);
+        }
+        if constexpr (EPI == EPI_LRELU) {          // tcnn CutlassMLP hidden activation (slope 0.01), PRE-FF:221-243
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.01f * v[r];
         }
         if constexpr (EPI == EPI_RES || EPI == EPI_BIAS_RES) {
             const uint2 rr = *reinterpret_cast<const uint2*>(residual + (int64_t)m * ldc + n);
@@ -448,6 +452,7 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
         D3D_GEMM_CASE(EPI_RES)
         D3D_GEMM_CASE(EPI_BIAS_RES)
         D3D_GEMM_CASE(EPI_SWIGLU)
+        D3D_GEMM_CASE(EPI_LRELU)
     }
 #undef D3D_GEMM_CASE
     d3d_set_error_("d3d_gemm_nt: unknown epilogue");

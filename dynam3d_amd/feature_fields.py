@@ -71,9 +71,31 @@ class Feature_Fields:
         return (float(self.args.zone_x_length), float(self.args.zone_y_length), float(self.args.zone_z_length))
 
     def load_state_dict(self, sd, strict: bool = True):
-        sd = {k: v for k, v in sd.items() if not k.startswith("FastSAM") and not k.startswith("nerf_")}
+        """Accepts the reference's keys (convert_ckpt.py).  Pretrain-only renderer keys (`nerf_*`,
+        `patch_to_nerf_*`, `aggregate_patch_to_nerf_*`) enable `render_view_3d_patch` when present."""
+        self._render_sd = {k: v for k, v in sd.items() if k.startswith(("nerf_", "patch_to_nerf_", "aggregate_patch_to_nerf_"))}
+        self._renderer = None
+        sd = {k: v for k, v in sd.items() if not k.startswith("FastSAM") and k not in self._render_sd}
         self.dense = FFDense(sd, self.device, n_head=int(self.args.fts_dim) // 64)
         return self
+
+    # ---- a20-a23: PRE-FF:494-625 ----------------------------------------------------------------------
+    @torch.no_grad()
+    def render_view_3d_patch(self, batch_position=None, batch_heading=None, batch_camera_intrinsic=None, batch_rot=None,
+                             batch_trans=None, visualization=False, debug=False, **render_kw):
+        """Novel-view 12x12 feature map rendered from the stored patches (Pretrain `Feature_Fields` surface).
+        Returns (features (B,12,12,768), positions (B,12,12,3), gt_labels=[]) like the reference (habitat mode)."""
+        if batch_rot is not None or batch_camera_intrinsic is not None:
+            raise NotImplementedError("intrinsics/extrinsics mode: SURVEY.md 8f-2")
+        if not getattr(self, "_render_sd", None):
+            raise RuntimeError("no renderer weights loaded (nerf_encoder/nerf_decoder/... keys of the Pretrain checkpoint)")
+        if self._renderer is None:
+            from .render import FieldRenderer
+            self._renderer = FieldRenderer(self._render_sd, self.device, **render_kw)
+        st = self.state
+        n_rows = [st.count(e, st.ROWS) for e in range(self.batch_size)]
+        out = self._renderer.render(self.pools, self.slots, n_rows, batch_position, batch_heading, self.ops, debug=debug)
+        return (out[0], out[1], []) + tuple(out[2:])
 
     def eval(self):
         return self

@@ -124,3 +124,16 @@ def ff_param_spec(width: int = 768):
     enc("aggregate_instance_to_zone_encoder")
     seq("instance_merge_discriminator", 2 * width + 3, 4 * width, 2)
     return spec
+
+
+def render_param_spec(width: int = 768, k: int = 4):
+    """Pretrain-only parameters of the novel-view renderer (PRE-FF:221-254).  The tcnn networks are stored as
+    per-layer [out,in] matrices `nerf_*.layers.{i}.weight` (tcnn itself keeps one flat `params` vector)."""
+    s = [("patch_to_nerf_position_embedding.0.weight", (width, 6)), ("patch_to_nerf_position_embedding.0.bias", (width,)),
+         ("patch_to_nerf_position_embedding.1.weight", (width,)), ("patch_to_nerf_position_embedding.1.bias", (width,)),
+         ("aggregate_patch_to_nerf_encoder.0.weight", (width, width * k)), ("aggregate_patch_to_nerf_encoder.0.bias", (width,)),
+         ("aggregate_patch_to_nerf_encoder.1.weight", (width,)), ("aggregate_patch_to_nerf_encoder.1.bias", (width,))]
+    s += [("nerf_encoder.layers.0.weight", (width, width)), ("nerf_encoder.layers.1.weight", (width, width)),
+          ("nerf_encoder.layers.2.weight", (width + 1, width))]
+    s += [(f"nerf_decoder.layers.{i}.weight", (width, width)) for i in range(3)]
+    return s

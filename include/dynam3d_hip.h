@@ -167,6 +167,11 @@ int32_t d3d_agent_frame_compact(const float* pool_pos_d, const float* pool_fts_d
 int32_t d3d_gemm_nt(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
                     int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
                     void* stream);
+/* same with an explicit tile (128 | 256); d3d_gemm_nt picks one (and splits the M remainder) itself.  epilogue 7 =
+ * LeakyReLU(0.01) for the tcnn CutlassMLP replacement. */
+int32_t d3d_gemm_nt_tile(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
+                         int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
+                         int32_t tile, void* stream);
 /* LayerNorm (rms = 0; clip/model.py:153-159: float32 statistics) or RMSNorm (rms = 1; Phi-3) over rows of D <= 4096 */
 int32_t d3d_norm(const void* x_d, const float* w_d, const float* b_d, void* y_d, int32_t rows, int32_t D, int64_t ldx,
                  int64_t ldy, float eps, int32_t rms, int32_t dtype, void* stream);
@@ -178,6 +183,33 @@ int32_t d3d_swiglu(const void* gate_up_d, void* out_d, int64_t rows, int32_t I, 
 /* a3 front-end (resnet_encoders.py:267-271): uint8 HWC -> bicubic SxS (rounded back to uint8) -> /255 -> normalise, f32 CHW */
 int32_t d3d_resize_normalize(const uint8_t* rgb_d, float* out_d, int32_t B, int32_t H, int32_t W, int32_t S,
                              const float* mean3_h, const float* std3_h, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pretrain novel-view renderer.  The 768-wide tcnn MLPs (PRE-FF:221-243, 484, 488) are
+ * d3d_gemm_nt launches with epilogue 7 (LeakyReLU 0.01, no bias), fp16.
+ * ---------------------------------------------------------------------------------------------- */
+/* a20 get_rays_habitat + world transform (PRE-FF:408-422, 524-530): float64 arithmetic rounded once.
+ * rel_y (N) f64 = linspace(near,far,N); tan_xy/tan_z (R) f32; pose64 (n_env,5) = cx,cy,cz,cos h,sin h -> ray (n_env,R,N,3) */
+int32_t d3d_rays_habitat(const double* rel_y_d, const float* tan_xy_d, const float* tan_z_d, const double* pose64_d,
+                         int32_t n_env, int32_t R, int32_t N, float* ray_xyz_d, void* stream);
+/* a21 importance sampling (PRE-FF:543-556): from the k-NN table (n_rays*N, k): dist = sqrt(d2), >= radius -> none;
+ * importance 1/sum(dist); top n_imp per ray by (importance desc, sample index asc) -> topk (n_rays,n_imp), neighbour
+ * ids of the chosen samples sidx (n_rays,n_imp,k) (-1 = none), n_ranked (n_rays) samples with a neighbour in range */
+int32_t d3d_ray_topk(const float* d2_d, const int32_t* idx_d, int32_t n_rays, int32_t N, int32_t k, float radius,
+                     int32_t n_imp, int32_t* topk_d, int32_t* sidx_d, int32_t* n_ranked_d, void* stream);
+/* a21/a22 front half (PRE-FF:586-616, 479-483): neighbour gather, 6-d relative geometry, Linear(6,768)+LayerNorm,
+ * fp16 add with the neighbour's fp16 feature -> s16 (n_rays*n_imp, k*768) fp16.  pose3 (n_env,3) = cos(-h),sin(-h),h */
+int32_t d3d_render_embed(const float* rows_pos_d, const float* rows_dir_d, const float* rows_scale_d, const uint16_t* rows_fts_d,
+                         int64_t n_cap, const int32_t* ray_slot_d, const int32_t* ray_env_d, const float* ray_xyz_d,
+                         const int32_t* topk_d, const int32_t* sidx_d, const float* pose3_d, const float* rel_direction_d,
+                         int32_t n_rays, int32_t R, int32_t N, int32_t n_imp, int32_t k, float far_, const float* w6_d,
+                         const float* b6_d, const float* ln_w_d, const float* ln_b_d, float eps, uint16_t* s16_d,
+                         float* geom6_d, float* sample_xyz_d, void* stream);
+/* a23 raw2feature (PRE-FF:446-474): softplus density, alpha compositing over the chosen samples, L2-normalised
+ * feature (n_rays,768) f32 and expected depth (n_rays).  feat/dens fp16 with row strides ldf/ldd (elements). */
+int32_t d3d_composite(const void* feat16_d, int64_t ldf, const void* dens16_d, int64_t ldd, const float* rel_dist_d,
+                      const int32_t* topk_d, int32_t n_rays, int32_t N, int32_t n_imp, float* feature_map_d, float* depth_d,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Host-side bookkeeping (ids / dict semantics of VLN-FF:357-393, 433-475, 623-691, 694-756).

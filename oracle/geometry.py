@@ -169,13 +169,23 @@ def knn_bruteforce(points: np.ndarray, queries: np.ndarray, k: int):
     M = q.shape[0]
     if k == 0 or p.shape[0] == 0:
         return np.zeros((M, 0), F32), np.zeros((M, 0), np.int64)
-    with np.errstate(over="ignore"):
-        dx = (q[:, None, 0] - p[None, :, 0]).astype(F32)
-        dy = (q[:, None, 1] - p[None, :, 1]).astype(F32)
-        dz = (q[:, None, 2] - p[None, :, 2]).astype(F32)
-        d2 = (((dx * dx).astype(F32) + (dy * dy).astype(F32)).astype(F32) + (dz * dz).astype(F32)).astype(F32)
-    idx = np.argsort(d2, axis=1, kind="stable")[:, :k]
-    return np.take_along_axis(d2, idx, axis=1), idx.astype(np.int64)
+    k = min(k, p.shape[0])
+    out_d, out_i = np.empty((M, k), F32), np.empty((M, k), np.int64)
+    chunk = max(1, (1 << 24) // max(p.shape[0], 1))
+    for a in range(0, M, chunk):
+        qq = q[a:a + chunk]
+        with np.errstate(over="ignore"):
+            dx = (qq[:, None, 0] - p[None, :, 0]).astype(F32)
+            dy = (qq[:, None, 1] - p[None, :, 1]).astype(F32)
+            dz = (qq[:, None, 2] - p[None, :, 2]).astype(F32)
+            d2 = (((dx * dx).astype(F32) + (dy * dy).astype(F32)).astype(F32) + (dz * dz).astype(F32)).astype(F32)
+        rows = np.arange(d2.shape[0])
+        for j in range(k):                      # k passes of argmin: first occurrence == lowest index on ties
+            i = np.argmin(d2, axis=1)
+            out_i[a:a + chunk, j] = i
+            out_d[a:a + chunk, j] = d2[rows, i]
+            d2[rows, i] = np.inf
+    return out_d, out_i
 
 
 # ---------------------------------------------------------------------------------------------

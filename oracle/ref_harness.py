@@ -64,7 +64,8 @@ class _BruteTree:
 
 
 class TcnnStub(torch.nn.Module):
-    """tinycudann.Network('CutlassMLP') stand-in: y = act(x W^T) per layer, no biases."""
+    """tinycudann.Network('CutlassMLP') stand-in DEFINING the parity target for a22: bias-free layers,
+    y = act(x W^T) with fp16 weights and activations, fp32 accumulation, fp16 store after every layer."""
 
     def __init__(self, n_input_dims, n_output_dims, network_config, seed=1337):
         super().__init__()
@@ -73,9 +74,7 @@ class TcnnStub(torch.nn.Module):
         dims = [n_input_dims] + [nn_] * nh + [n_output_dims]
         self.act = network_config.get("activation", "None")
         self.out_act = network_config.get("output_activation", "None")
-        self.weights = torch.nn.ParameterList(
-            [torch.nn.Parameter(torch.randn(dims[i + 1], dims[i]) * dims[i] ** -0.5) for i in range(len(dims) - 1)]
-        )
+        self.layers = torch.nn.ModuleList([torch.nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(len(dims) - 1)])
 
     @staticmethod
     def _apply(name, x):
@@ -88,10 +87,11 @@ class TcnnStub(torch.nn.Module):
         raise NotImplementedError(name)
 
     def forward(self, x):
-        h = x
-        for i, w in enumerate(self.weights):
-            h = h.to(w.dtype) @ w.t()
-            h = self._apply(self.act if i < len(self.weights) - 1 else self.out_act, h)
+        h = x.to(torch.float16)
+        for i, l in enumerate(self.layers):
+            y = h.float() @ l.weight.to(torch.float16).float().t()
+            y = self._apply(self.act if i < len(self.layers) - 1 else self.out_act, y)
+            h = y.to(torch.float16)
         return h
 
 

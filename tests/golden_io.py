@@ -48,3 +48,25 @@ def unpack_ragged(flat, off):
 
 def load(name):
     return np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
+
+
+RENDER_CASES = {
+    # name: synthetic scene + view settings for the Pretrain renderer goldens (g6)
+    "small": dict(seed=21, n_points=576 * 2, H=6, W=6, n_samples=101, position=[0.2, 0.0, -0.4], heading=0.6),
+    "full": dict(seed=22, n_points=576 * 6, H=12, W=12, n_samples=501, position=[0.3, 0.1, -0.2], heading=1.1),
+}
+
+
+def render_scene(case):
+    """Stored patches of one environment: positions on a ring of surfaces around the origin (+ tomb-stones),
+    directions, scales and fp16 features -- regenerated from the seed."""
+    import math
+    rng = np.random.default_rng(case["seed"])
+    N = case["n_points"]
+    ang, rad = rng.uniform(0, 2 * math.pi, N), rng.uniform(0.8, 3.5, N)
+    pos = np.stack([rad * np.cos(ang), rad * np.sin(ang), rng.uniform(-1.2, 1.2, N)], -1).astype(np.float32)
+    pos[::37] = -10000.0
+    pdir = rng.uniform(0, 2 * math.pi, N).astype(np.float32)
+    psc = rng.uniform(0.01, 0.3, N).astype(np.float32)
+    fts = rng.standard_normal((N, 768)).astype(np.float16)
+    return pos, pdir, psc, fts
