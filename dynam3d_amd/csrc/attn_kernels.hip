@@ -1,0 +1,322 @@
+// attn_kernels.hip -- fused (flash-style) self-attention forward for gfx950: bf16/fp16, head_dim 64 (ViT-L towers) and
+// 96 (Phi-3-mini), causal or full, reading q/k/v straight out of the fused QKV projection buffer (no transposes,
+// no materialised S x S scores).
+//
+// Mapping (wave64, v_mfma_f32_16x16x32):
+//   * workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 queries (two 16-wide q-tiles) whose
+//     Q fragments stay in registers; K/V tiles of 64 keys are staged once per workgroup in LDS.
+//   * scores are computed TRANSPOSED: S^T = K . Q^T  (A = K fragment, B = Q fragment), so a lane holds, for ONE query
+//     (column lane&15), keys 4*(lane>>4)+r of every 16-key tile: the softmax row reduction is register-local plus two
+//     xor-shuffles (lanes +-16, +-32), and P^T is already in the B-operand layout of the second product
+//     O^T = V^T . P^T  (A = V^T fragment from a transposed LDS image, B = P^T packed to 16 bit).
+//   * the k-slot order inside a 32-deep MFMA step is a free permutation as long as A and B agree; here slots 0-3 are
+//     keys 4g..4g+3 of the even 16-key tile and slots 4-7 the same rows of the odd tile (g = lane>>4), which is exactly
+//     what the S^T accumulators hold -- no cross-lane data movement between the two GEMMs.
+//   * O^T accumulators put 4 consecutive head-dim elements of one query in a lane: 8-byte packed stores.
+//   * K rows are XOR-swizzled on 16-byte chunks, V^T rows padded by 4 elements: conflict-free ds_read_b128 / ds_read_b64.
+//   * V is pre-transposed once per layer (k_transpose_v); K/V^T tiles are prefetched into registers one tile ahead.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/dynam3d_hip.h"
+#include "d3d_common.h"
+
+namespace {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using float4v = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BQ = 128, BKV = 64, NT = 256;
+
+template <bool BF16>
+__device__ __forceinline__ float4v mfma16(const uint4& a, const uint4& b, float4v c) {
+    if constexpr (BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&a), *reinterpret_cast<const half8*>(&b), c, 0, 0, 0);
+}
+
+template <bool BF16>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    if constexpr (BF16) {
+        uint32_t r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));      // RNE, one VALU op per pair (no builtin on gfx950)
+        return r;
+    } else {
+        const __half2 h = __floats2half2_rn(lo, hi);
+        return *reinterpret_cast<const uint32_t*>(&h);
+    }
+}
+
+// V (B,S,.,hd) token-major  ->  V^T (B,H,hd,Sp) key-major (Sp = S rounded up to 64, tail zero-filled), once per layer:
+// the MFMA A-operand of O^T = V^T P^T needs 8 consecutive KEYS per lane, so the transposition is done once here
+// (each element passes LDS one time) instead of once per query block inside the attention kernel.
+template <int HD>
+__global__ void __launch_bounds__(256)
+k_transpose_v(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ vt, int S, int Sp, int H, int64_t row_stride, int64_t batch_stride,
+              int v_off) {
+    constexpr int CH = HD / 8;
+    __shared__ uint16_t tile[HD][64 + 2];
+    const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const uint16_t* Vp = qkv + (int64_t)b * batch_stride + (int64_t)(v_off + h) * HD;
+    for (int c = threadIdx.x; c < 64 * CH; c += 256) {
+        const int key = c / CH, dc = c % CH;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k0 + key < S) v = *reinterpret_cast<const uint4*>(Vp + (int64_t)(k0 + key) * row_stride + dc * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[dc * 8 + j][key] = (uint16_t)(w[j >> 1] >> ((j & 1) * 16));
+    }
+    __syncthreads();
+    uint16_t* dst = vt + (((int64_t)b * H + h) * HD) * Sp + k0;
+    for (int c = threadIdx.x; c < HD * 8; c += 256) {        // 8 chunks of 8 keys per head-dim row
+        const int d = c / 8, kc = c % 8;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (uint32_t)tile[d][kc * 8 + 2 * j] | ((uint32_t)tile[d][kc * 8 + 2 * j + 1] << 16);
+        *reinterpret_cast<uint4*>(dst + (int64_t)d * Sp + kc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+template <bool BF16, int HD, bool CAUSAL>
+__global__ void __launch_bounds__(NT, 2)          // 2 waves/SIMD = 2 workgroups per CU: keep VGPR+AGPR <= 256
+k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, int Sp, uint16_t* __restrict__ out, int S, int H,
+             int64_t row_stride /* elements between tokens */, int64_t batch_stride, int q_off, int k_off, float scale_log2e, int seq_len) {
+    // K rows are padded to a power-of-two number of 16-byte chunks and XOR-swizzled (chunk ^= row & (KCH-1)): every
+    // ds_read_b128 lane group (which mixes two k-groups, e.g. lanes {0-3,12-15,20-27}) then hits 16 distinct slots.
+    constexpr int KCH = HD == 96 ? 16 : 8;   // chunk positions per LDS row
+    constexpr int KST = KCH * 8;             // K row stride (elements): 256 B (hd 96) / 128 B (hd 64)
+    constexpr int VST = BKV + 4;             // V^T row stride 136 B: dword stride 34 -> conflict-free 8-byte reads
+    constexpr int DS = HD / 32;          // 32-deep steps over head_dim (QK^T)
+    constexpr int DT = HD / 16;          // 16-wide head-dim tiles (PV)
+    constexpr int CH = HD / 8;           // 16-byte chunks per row
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[BKV * KST];
+    __shared__ __attribute__((aligned(16))) uint16_t Vt[HD * VST];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    // causal: late query blocks have the most key tiles -> dispatch them first so the short ones fill the tail
+    const int qb = CAUSAL ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = qb * BQ, qw = q0 + wave * 32;
+    const uint16_t* base = qkv + (int64_t)b * batch_stride;
+    const uint16_t* Qp = base + (int64_t)(q_off + h) * HD;
+    const uint16_t* Kp = base + (int64_t)(k_off + h) * HD;
+    const uint16_t* Vtp = vt + (((int64_t)b * H + h) * HD) * Sp;          // (hd, Sp) key-major
+
+    // Q fragments (B operand): lane holds Q[q = qw + qt*16 + fi][d = ks*32 + fg*8 .. +7]
+    uint4 qf[2][DS];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int q = qw + qt * 16 + fi;
+        q = q < S ? q : S - 1;
+#pragma unroll
+        for (int ks = 0; ks < DS; ++ks) qf[qt][ks] = *reinterpret_cast<const uint4*>(Qp + (int64_t)q * row_stride + ks * 32 + fg * 8);
+    }
+    float4v oacc[2][DT];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] = float4v{0.f, 0.f, 0.f, 0.f};
+    float m_i[2] = {-INFINITY, -INFINITY}, l_i[2] = {0.f, 0.f};
+
+    const int kv_len = CAUSAL ? min(seq_len, q0 + BQ) : seq_len;
+    const int n_tiles = (kv_len + BKV - 1) / BKV;
+
+    // register-staged prefetch (issue-early / write-late): tile t+1 is loaded into VGPRs before tile t is computed and
+    // written to LDS after it, so the global-load latency hides under the MFMA + softmax work of the current tile.
+    constexpr int NK = (BKV * CH) / NT, NV = (HD * 8) / NT;      // 3,3 (hd 96) or 2,2 (hd 64) 16-byte chunks per thread
+    static_assert(NK <= 3 && NV <= 3, "tile shape");
+    // named scalars (not arrays: loop-carried uint4 arrays were left in scratch memory by the compiler)
+    uint4 kr0, kr1, kr2 = make_uint4(0, 0, 0, 0), vr0, vr1, vr2 = make_uint4(0, 0, 0, 0);
+    auto ld_k = [&](int key0_, int i) -> uint4 {
+        const int c = tid + i * NT;
+        int kr = key0_ + c / CH;
+        kr = kr < S ? kr : S - 1;
+        return *reinterpret_cast<const uint4*>(Kp + (int64_t)kr * row_stride + (c % CH) * 8);
+    };
+    auto ld_v = [&](int key0_, int i) -> uint4 {
+        const int c = tid + i * NT;                                                                // (d, 8-key chunk)
+        return *reinterpret_cast<const uint4*>(Vtp + (int64_t)(c >> 3) * Sp + key0_ + (c & 7) * 8);
+    };
+    auto st_k = [&](int i, const uint4& v) {
+        const int c = tid + i * NT;
+        const int r = c / CH;
+        *reinterpret_cast<uint4*>(Ks + r * KST + (((c % CH) ^ (r & (KCH - 1))) << 3)) = v;         // swizzled K rows
+    };
+    auto st_v = [&](int i, const uint4& v) {
+        const int c = tid + i * NT;
+        uint16_t* d = Vt + (c >> 3) * VST + (c & 7) * 8;                                          // V^T rows of 64 keys (8-byte aligned)
+        *reinterpret_cast<uint2*>(d) = make_uint2(v.x, v.y);
+        *reinterpret_cast<uint2*>(d + 4) = make_uint2(v.z, v.w);
+    };
+#define FA_LOAD_TILE(T)                                       \
+    {                                                         \
+        const int k0_ = (T) * BKV;                            \
+        kr0 = ld_k(k0_, 0);                                   \
+        kr1 = ld_k(k0_, 1);                                   \
+        if constexpr (NK > 2) kr2 = ld_k(k0_, 2);             \
+        vr0 = ld_v(k0_, 0);                                   \
+        vr1 = ld_v(k0_, 1);                                   \
+        if constexpr (NV > 2) vr2 = ld_v(k0_, 2);             \
+    }
+
+    FA_LOAD_TILE(0)
+    for (int t = 0; t < n_tiles; ++t) {
+        const int key0 = t * BKV;
+        __syncthreads();                                   // every wave is done reading the previous tile
+        st_k(0, kr0);
+        st_k(1, kr1);
+        if constexpr (NK > 2) st_k(2, kr2);
+        st_v(0, vr0);
+        st_v(1, vr1);
+        if constexpr (NV > 2) st_v(2, vr2);
+        __syncthreads();
+        if (t + 1 < n_tiles) FA_LOAD_TILE(t + 1)
+        if (CAUSAL && key0 > qw + 31) continue;            // whole tile above this wave's diagonal (wave-uniform)
+        // masking is only needed on the diagonal tiles of this wave and on the tile that crosses seq_len
+        const bool need_mask = (CAUSAL && key0 + BKV - 1 > qw) || (key0 + BKV > seq_len);
+
+        // ---- S^T = K Q^T : st[qt][kt] holds keys key0 + kt*16 + 4*fg + r for query qw + qt*16 + fi ------------
+        float4v st[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            uint4 kf[DS];
+#pragma unroll
+            for (int ks = 0; ks < DS; ++ks) {
+                const int r = kt * 16 + fi;
+                kf[ks] = *reinterpret_cast<const uint4*>(Ks + r * KST + (((ks * 4 + fg) ^ (r & (KCH - 1))) << 3));
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                float4v a = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < DS; ++ks) a = mfma16<BF16>(kf[ks], qf[qt][ks], a);
+                st[qt][kt] = a;
+            }
+        }
+        // ---- online softmax in base 2 on the raw scores: p = exp2(s*c - m*c), c = log2(e)/sqrt(hd) ---------------------
+        uint4 pf[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            if (need_mask) {
+                const int q = qw + qt * 16 + fi;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + kt * 16 + fg * 4 + r;
+                        if (key >= seq_len || (CAUSAL && key > q)) st[qt][kt][r] = -INFINITY;
+                    }
+            }
+            float tmax = fmaxf(fmaxf(st[qt][0][0], st[qt][0][1]), fmaxf(st[qt][0][2], st[qt][0][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt) tmax = fmaxf(tmax, fmaxf(fmaxf(st[qt][kt][0], st[qt][kt][1]), fmaxf(st[qt][kt][2], st[qt][kt][3])));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            // deferred max: keep the old running max while the tile max exceeds it by < 2^8 (P stays <= 256, fine for the
+            // fp32 accumulators and the 16-bit P operand); the O / l rescale is then skipped for the whole wave.
+            const float tm = tmax * scale_log2e;                              // scaled units (scale > 0 keeps the max)
+            const bool keep = __all(tm <= m_i[qt] + 8.0f);
+            const float m_new = keep ? m_i[qt] : fmaxf(m_i[qt], tm);
+            const float alpha = keep ? 1.0f : __builtin_amdgcn_exp2f(m_i[qt] - m_new);
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(st[qt][kt][r], scale_log2e, -m_new));
+                    st[qt][kt][r] = p;
+                    rs += p;
+                }
+            rs += __shfl_xor(rs, 16);
+            rs += __shfl_xor(rs, 32);
+            l_i[qt] = l_i[qt] * alpha + rs;
+            m_i[qt] = m_new;
+            if (!keep) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oacc[qt][dt][r] *= alpha;
+            }
+            // P^T as B operand: k-step kp covers key tiles 2kp (slots 0-3) and 2kp+1 (slots 4-7)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                pf[qt][kp].x = pack2<BF16>(st[qt][2 * kp][0], st[qt][2 * kp][1]);
+                pf[qt][kp].y = pack2<BF16>(st[qt][2 * kp][2], st[qt][2 * kp][3]);
+                pf[qt][kp].z = pack2<BF16>(st[qt][2 * kp + 1][0], st[qt][2 * kp + 1][1]);
+                pf[qt][kp].w = pack2<BF16>(st[qt][2 * kp + 1][2], st[qt][2 * kp + 1][3]);
+            }
+        }
+        // ---- O^T += V^T P^T ------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const uint16_t* vrow = Vt + (dt * 16 + fi) * VST + kp * 32 + fg * 4;
+                const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) oacc[qt][dt] = mfma16<BF16>(vf, pf[qt][kp], oacc[qt][dt]);
+            }
+        }
+    }
+#undef FA_LOAD_TILE
+    // ---- epilogue: lane holds O[q = qw + qt*16 + fi][d = dt*16 + 4*fg + r] -----------------------------------------------
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = qw + qt * 16 + fi;
+        if (q >= S) continue;
+        const float inv = 1.0f / l_i[qt];
+        uint16_t* op = out + (((int64_t)b * S + q) * H + h) * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            uint2 o;
+            o.x = pack2<BF16>(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv);
+            o.y = pack2<BF16>(oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv);
+            *reinterpret_cast<uint2*>(op + dt * 16 + fg * 4) = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Self-attention over a fused projection buffer.  qkv: (B, S, Htot, hd) 16-bit with q heads at [q_off, q_off+H), k heads
+// at [k_off, ..), v heads at [v_off, ..); token stride = row_stride elements, batch stride = batch_stride elements.
+// out: (B, S, H, hd) contiguous.  seq_len = number of valid keys (<= S).  dtype 0 = bf16, 1 = fp16; hd in {64, 96}.
+// vt_scratch: caller-provided (B, H, hd, Sp) 16-bit workspace, Sp = S rounded up to 64 (the pre-transposed V).
+int32_t d3d_flash_attention(const void* qkv, void* out, void* vt_scratch, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride,
+                            int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
+                            int32_t dtype, void* stream) {
+    if (B <= 0 || S <= 0) return D3D_OK;
+    if ((head_dim != 64 && head_dim != 96) || (row_stride & 7) || (batch_stride & 7)) {
+        d3d_set_error_("d3d_flash_attention: head_dim must be 64 or 96; strides multiples of 8 elements");
+        return D3D_EINVAL;
+    }
+    const float sl2 = 1.4426950408889634f / sqrtf((float)head_dim);
+    const int Sp = (S + 63) / 64 * 64;
+    hipStream_t s = (hipStream_t)stream;
+    const uint16_t* q = (const uint16_t*)qkv;
+    uint16_t* o = (uint16_t*)out;
+    uint16_t* vt = (uint16_t*)vt_scratch;
+    dim3 tg(Sp / 64, H, B);
+    if (head_dim == 96) hipLaunchKernelGGL(k_transpose_v<96>, tg, dim3(256), 0, s, q, vt, S, Sp, H, row_stride, batch_stride, v_off);
+    else hipLaunchKernelGGL(k_transpose_v<64>, tg, dim3(256), 0, s, q, vt, S, Sp, H, row_stride, batch_stride, v_off);
+    dim3 grid((S + BQ - 1) / BQ, H, B), block(NT);
+#define D3D_FA(BF, HDV, CA) hipLaunchKernelGGL((k_flash_attn<BF, HDV, CA>), grid, block, 0, s, q, vt, Sp, o, S, H, row_stride, batch_stride, q_off, k_off, sl2, seq_len)
+    if (dtype == 0) {
+        if (head_dim == 96) { if (causal) D3D_FA(true, 96, true); else D3D_FA(true, 96, false); }
+        else { if (causal) D3D_FA(true, 64, true); else D3D_FA(true, 64, false); }
+    } else {
+        if (head_dim == 96) { if (causal) D3D_FA(false, 96, true); else D3D_FA(false, 96, false); }
+        else { if (causal) D3D_FA(false, 64, true); else D3D_FA(false, 64, false); }
+    }
+#undef D3D_FA
+    D3D_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -210,6 +210,65 @@ __global__ void k_swiglu(const uint16_t* __restrict__ gu, uint16_t* __restrict__
     *reinterpret_cast<uint4*>(out + i) = *reinterpret_cast<const uint4*>(o);
 }
 
+// Variable-length self-attention over packed token sets (the patch->instance / instance->zone set encoders,
+// VLN-FF:134-155): float32, head_dim 64, no mask inside a set, softmax scale 1/8.  qkv (T, 3*H*64) packed
+// [q | k | v]; set g owns tokens [off[g], off[g+1]).  One workgroup per (set, head, 64-query tile): every thread
+// owns one query row in registers (q, running max/sum, 64-wide output accumulator) and streams the set's keys and
+// values through LDS in tiles of 64 (online softmax).  `q_rows` limits the queries to the first rows of each set
+// (1 = CLS only, for the last layer whose other rows are never read).
+__global__ void __launch_bounds__(64)
+k_set_attention(const float* __restrict__ qkv, const int32_t* __restrict__ off, int H, int q_rows, float* __restrict__ out) {
+    constexpr int HD = 64, TK = 64;
+    __shared__ float ks[TK][HD + 1];
+    __shared__ float vs[TK][HD + 1];
+    const int g = blockIdx.x, h = blockIdx.y, qt = blockIdx.z;
+    const int t0 = off[g], L = off[g + 1] - t0;
+    const int nq = q_rows > 0 ? min(q_rows, L) : L;
+    if (qt * 64 >= nq) return;
+    const int qi = qt * 64 + threadIdx.x;
+    const bool active = qi < nq;
+    const int64_t ld = (int64_t)3 * H * HD;
+    float q[HD], o[HD];
+    float m = -INFINITY, l = 0.f;
+    if (active) {
+        const float* qp = qkv + (int64_t)(t0 + qi) * ld + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) q[d] = qp[d] * 0.125f;
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    for (int k0 = 0; k0 < L; k0 += TK) {
+        const int cnt = min(TK, L - k0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt * HD; i += 64) {
+            const int r = i / HD, d = i % HD;
+            const float* base = qkv + (int64_t)(t0 + k0 + r) * ld + h * HD + d;
+            ks[r][d] = base[H * HD];
+            vs[r][d] = base[2 * H * HD];
+        }
+        __syncthreads();
+        if (active) {
+            for (int r = 0; r < cnt; ++r) {
+                float sdot = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) sdot += q[d] * ks[r][d];
+                const float mn = fmaxf(m, sdot);
+                const float a = __expf(m - mn), p = __expf(sdot - mn);
+                l = l * a + p;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) o[d] = o[d] * a + p * vs[r][d];
+                m = mn;
+            }
+        }
+    }
+    if (active) {
+        const float inv = 1.0f / l;
+        float* op = out + (int64_t)(t0 + qi) * (H * HD) + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) op[d] = o[d] * inv;
+    }
+}
+
 template <bool BF16, bool RMS>
 int32_t launch_norm(const void* x, const float* w, const float* b, void* y, int rows, int D, int64_t ldx, int64_t ldy, float eps,
                     hipStream_t s) {
@@ -279,6 +338,15 @@ int32_t d3d_swiglu(const void* gate_up, void* out, int64_t rows, int32_t I, int3
         hipLaunchKernelGGL(k_swiglu<true>, grid, block, 0, (hipStream_t)stream, (const uint16_t*)gate_up, (uint16_t*)out, rows, I);
     else
         hipLaunchKernelGGL(k_swiglu<false>, grid, block, 0, (hipStream_t)stream, (const uint16_t*)gate_up, (uint16_t*)out, rows, I);
+    D3D_LAUNCH_CHECK();
+}
+
+int32_t d3d_set_attention(const float* qkv, const int32_t* set_off, int32_t n_sets, int32_t n_heads, int32_t max_len, int32_t q_rows,
+                          float* out, void* stream) {
+    if (n_sets <= 0 || max_len <= 0) return D3D_OK;
+    const int nq = q_rows > 0 ? (q_rows < max_len ? q_rows : max_len) : max_len;
+    dim3 grid(n_sets, n_heads, (nq + 63) / 64);
+    hipLaunchKernelGGL(k_set_attention, grid, dim3(64), 0, (hipStream_t)stream, qkv, set_off, n_heads, q_rows, out);
     D3D_LAUNCH_CHECK();
 }
 

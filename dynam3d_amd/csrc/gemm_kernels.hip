@@ -264,7 +264,8 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
 // ================================================================================================
 constexpr int TM = 256, TN = 256, T_THREADS = 512;
 
-template <bool BF16, int EPI>
+// DBG (timing experiments only, wrong results): 1 = no LDS-DMA inside the loop, 2 = DMA issued but never waited for
+template <bool BF16, int EPI, bool KFULL = false, int DBG = 0>
 __global__ void __launch_bounds__(T_THREADS, 2)
 k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* __restrict__ C,
               const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, int M, int N, int K, int64_t lda,
@@ -295,30 +296,29 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
-    uint4 af[8], bf[4];
+    constexpr int NH = KFULL ? 2 : 1;          // K-halves held in registers per step
+    uint4 af[NH][8], bf[NH][4];
 
     // LOAD(t, kk): the 12 fragments of K-half kk (32 deep) of tile t -> 48 VGPRs
-    auto LOAD = [&](int t, int kk) {
+    auto LOAD = [&](int t, int kk, int slot) {
         const uint16_t* la = smem + (t & 1) * BUF;
         const uint16_t* lb = la + TM * BK;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int rb = wn * 64 + j * 16 + fi;
-            bf[j] = *reinterpret_cast<const uint4*>(lb + rb * BK + (((kk * 4 + fg) ^ (rb & 7)) << 3));
+            bf[slot][j] = *reinterpret_cast<const uint4*>(lb + rb * BK + (((kk * 4 + fg) ^ (rb & 7)) << 3));
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ra = grp * 128 + i * 16 + fi;
-            af[i] = *reinterpret_cast<const uint4*>(la + ra * BK + (((kk * 4 + fg) ^ (ra & 7)) << 3));
+            af[slot][i] = *reinterpret_cast<const uint4*>(la + ra * BK + (((kk * 4 + fg) ^ (ra & 7)) << 3));
         }
     };
-    auto COMPUTE = [&]() {
-        __builtin_amdgcn_s_setprio(1);
+    auto COMPUTE = [&](int slot) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<BF16>(bf[j], af[i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<BF16>(bf[slot][j], af[slot][i], acc[i][j]);
     };
 
     const int nk = K / BK;
@@ -328,29 +328,47 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ONE instruction stream for both groups: LOAD(half) | barrier | COMPUTE | barrier ...; group 1 executes one
-    // extra barrier up front, so it always runs exactly one step behind group 0 (and group 0 one extra at the
-    // end).  Tile t+1 goes in flight at the start of tile t and must have landed one step before group 0 reads it:
-    // group 0 drains its share at the end of its 4th step, group 1 (a step late) at the end of its 3rd.
+    // ONE instruction stream for both groups: LOAD | barrier | COMPUTE | barrier ...; group 1 executes one extra
+    // barrier up front, so it always runs exactly one step behind group 0 (and group 0 one extra at the end).
+    // Tile t+1 goes in flight at the start of tile t and must have landed one step before group 0 reads it:
+    // group 0 drains its share at the end of its last step of the tile, group 1 (a step late) one step earlier.
     if (grp == 1) __builtin_amdgcn_s_barrier();
     for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) {
+        if (DBG != 1 && t + 1 < nk) {
             const uint32_t nxt = lds0 + ((t + 1) & 1) * (BUF * 2);
             stage_tile_dma<8>(A, lda, row0, M, (t + 1) * BK, nxt, wave, lane);
             stage_tile_dma<8>(W, ldw, col0, N, (t + 1) * BK, nxt + TM * BK * 2, wave, lane);
         }
-        LOAD(t, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        COMPUTE();
-        __builtin_amdgcn_s_barrier();
-        LOAD(t, 1);
-        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        COMPUTE();
-        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (KFULL) {
+            LOAD(t, 0, 0);
+            LOAD(t, 1, 1);
+            if (DBG == 0 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            COMPUTE(0);
+            COMPUTE(1);
+            __builtin_amdgcn_s_setprio(0);
+            if (DBG == 0 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            LOAD(t, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            COMPUTE(0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            LOAD(t, 1, 0);
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            COMPUTE(0);
+            __builtin_amdgcn_s_setprio(0);
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
 
@@ -368,17 +386,17 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     }
 }
 
-template <bool BF16, int EPI>
+template <bool BF16, int EPI, bool KFULL = false, int DBG = 0>
 int32_t launch256(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
                   int64_t ldw, int64_t ldc, hipStream_t s) {
     const int tm = (M + TM - 1) / TM, tn = N / TN;
     const size_t sh = 2 * 2 * TM * BK * sizeof(uint16_t);   // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, KFULL, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
+    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL, DBG>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
                        (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn);
     D3D_LAUNCH_CHECK();
 }
@@ -428,7 +446,7 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
 int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream) {
     if (M <= 0) return D3D_OK;
-    if (tile == 256 && N % TN != 0) {
+    if (tile >= 256 && N % TN != 0) {
         d3d_set_error_("d3d_gemm_nt_tile: tile 256 needs N % 256 == 0");
         return D3D_EINVAL;
     }
@@ -439,7 +457,13 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
     hipStream_t s = (hipStream_t)stream;
 #define D3D_GEMM_CASE(E)                                                                                              \
     case E:                                                                                                           \
-        if (tile == 256)                                                                                              \
+        if (tile == 257 && dtype == 0 && (E == EPI_NONE || E == EPI_SWIGLU))                                          \
+            return launch256<true, E, true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);                       \
+        if (tile == 258 && dtype == 0 && E == EPI_NONE)                                                                \
+            return launch256<true, E, true, 1>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);                    \
+        if (tile == 259 && dtype == 0 && E == EPI_NONE)                                                                \
+            return launch256<true, E, true, 2>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);                    \
+        if (tile >= 256)                                                                                              \
             return dtype == 0 ? launch256<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)                 \
                               : launch256<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);               \
         return dtype == 0 ? launch<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)                        \

@@ -82,10 +82,17 @@ def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool) -> torch.Tensor:
     """q,k,v (B,L,H,hd) (any strides) -> (B,L,H,hd) contiguous; softmax scale 1/sqrt(hd)."""
-    if BACKEND["attention"] == "hip" and q.is_cuda:
-        return _hip.attention(q, k, v, causal)
     o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), is_causal=causal)
     return o.transpose(1, 2).contiguous()
+
+
+def attention_qkv(qkv: torch.Tensor, n_heads: int, causal: bool) -> torch.Tensor:
+    """Self-attention over the fused projection qkv (B,S,3H,hd) laid out [q heads | k heads | v heads] -> (B,S,H,hd).
+    HIP backend: flash kernel reading q/k/v in place (csrc/attn_kernels.hip); otherwise SDPA on strided views."""
+    B, S, Ht, hd = qkv.shape
+    if BACKEND["attention"] == "hip" and qkv.is_cuda and Ht == 3 * n_heads and _hip.attention_ok(qkv, hd):
+        return _hip.attention_qkv(qkv, n_heads, causal)
+    return attention(qkv[:, :, :n_heads], qkv[:, :, n_heads:2 * n_heads], qkv[:, :, 2 * n_heads:], causal)
 
 
 def rope_qk_(qkv: torch.Tensor, n_rot_heads: int, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:

@@ -19,6 +19,7 @@ class FFDense:
         self.w = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         self.n_head = n_head
         self.width = self.w["aggregate_patch_to_instance_embedding"].shape[-1]
+        self._hd = None
 
     # nn.Sequential(Linear, LayerNorm, GELU, Linear)
     def mlp(self, x: torch.Tensor, name: str) -> torch.Tensor:
@@ -47,14 +48,57 @@ class FFDense:
 
     def encode_sets(self, emb: torch.Tensor, lens: Sequence[int], which: str) -> torch.Tensor:
         """emb (T,768): member-token embeddings of G groups laid out back to back; lens[g] members.
-        Returns (G,768) = encoder([CLS; members_g])[0].  Groups are bucketed by power-of-two length so
-        one long merged set does not pad the whole batch."""
+        Returns (G,768) = encoder([CLS; members_g])[0].
+
+        Device path: all sets are PACKED ([CLS; members] back to back, no padding); the linears / norms run once over
+        the packed tokens and self-attention runs inside each set with the varlen HIP kernel (d3d_set_attention).
+        The last layer only evaluates the CLS rows (the only rows the reference keeps, VLN-FF:595)."""
+        G = len(lens)
+        if G == 0:
+            return torch.empty((0, self.width), dtype=torch.float32, device=self.device)
+        if self.device.type != "cuda":
+            return self._encode_sets_padded(emb, lens, which)
+        if self._hd is None:
+            from .hip_dense import HipDense
+            self._hd = HipDense()
+        w, H, D = self.w, self.n_head, self.width
+        enc = f"aggregate_{which}_encoder"
+        cls = w[f"aggregate_{which}_embedding"]
+        lens = np.asarray(lens, np.int64)
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        T = int(offs[-1])
+        poff = offs + np.arange(G + 1)                                    # packed offsets (one CLS per set)
+        idx = np.empty(T + G, np.int64)
+        cls_rows = poff[:-1]
+        idx[cls_rows] = T                                                 # row T of `src` is the CLS embedding
+        member = np.ones(T + G, bool)
+        member[cls_rows] = False
+        idx[member] = np.arange(T)
+        dev = self.device
+        src = torch.cat([emb, cls], 0)
+        x = src.index_select(0, torch.from_numpy(idx).to(dev))
+        set_off = torch.from_numpy(poff.astype(np.int32)).to(dev)
+        cls_t = torch.from_numpy(cls_rows).to(dev)
+        max_len = int(lens.max()) + 1
+        for i in range(2):
+            p = f"{enc}.layers.{i}"
+            last = i == 1
+            qkv = F.linear(x, w[p + ".self_attn.in_proj_weight"], w[p + ".self_attn.in_proj_bias"])
+            a = self._hd.set_attention(qkv, set_off, G, H, max_len, q_rows=1 if last else 0)
+            if last:                                                      # only the CLS rows feed the output
+                a, x = a.index_select(0, cls_t), x.index_select(0, cls_t)
+            a = F.linear(a, w[p + ".self_attn.out_proj.weight"], w[p + ".self_attn.out_proj.bias"])
+            x = F.layer_norm(x + a, (D,), w[p + ".norm1.weight"], w[p + ".norm1.bias"], 1e-5)
+            h = F.linear(F.gelu(F.linear(x, w[p + ".linear1.weight"], w[p + ".linear1.bias"])), w[p + ".linear2.weight"], w[p + ".linear2.bias"])
+            x = F.layer_norm(x + h, (D,), w[p + ".norm2.weight"], w[p + ".norm2.bias"], 1e-5)
+        return F.layer_norm(x, (D,), w[enc + ".norm.weight"], w[enc + ".norm.bias"], 1e-12)
+
+    def _encode_sets_padded(self, emb: torch.Tensor, lens: Sequence[int], which: str) -> torch.Tensor:
+        """Host-logic path used by the CPU tests (tests/cpu_ops.py): same arithmetic on padded buckets."""
         enc = f"aggregate_{which}_encoder"
         cls = self.w[f"aggregate_{which}_embedding"]
         G = len(lens)
         out = torch.empty((G, self.width), dtype=torch.float32, device=self.device)
-        if G == 0:
-            return out
         lens = np.asarray(lens, np.int64)
         offs = np.concatenate([[0], np.cumsum(lens)])
         T = int(offs[-1])

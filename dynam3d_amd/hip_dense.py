@@ -15,6 +15,8 @@ _lib.register("d3d_gemm_nt", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, 
 _lib.register("d3d_gemm_nt_tile", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32, vp])
 _lib.register("d3d_norm", [vp, vp, vp, vp, i32, i32, i64, i64, f32, i32, i32, vp])
 _lib.register("d3d_rope_inplace", [vp, vp, vp, i32, i32, i32, i32, i64, i32, vp])
+_lib.register("d3d_set_attention", [vp, vp, i32, i32, i32, i32, vp, vp])
+_lib.register("d3d_flash_attention", [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, i32, vp])
 _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
 _lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
 
@@ -32,7 +34,7 @@ def interleave_gate_up(w: torch.Tensor, block: int = 16) -> torch.Tensor:
 
 
 class HipDense:
-    PRIMS = {"linear", "layer_norm", "rms_norm", "rope", "swiglu", "resize_normalize"}
+    PRIMS = {"linear", "layer_norm", "rms_norm", "rope", "swiglu", "resize_normalize", "attention"}
 
     def __init__(self):
         self.lib = _lib.load()
@@ -62,6 +64,10 @@ class HipDense:
         dt = 0 if x.dtype == torch.bfloat16 else 1
         if self.TILE:
             tile = self.TILE if (self.TILE == 128 or N % 256 == 0) else 128
+            if tile == 257 and epi not in ('none', 'swiglu'):
+                tile = 256
+            if tile in (258, 259) and epi != 'none':
+                tile = 256
             _lib.check(self.lib.d3d_gemm_nt_tile(_p(x), _p(w), _p(out), _p(bias), _p(residual), M, N, K, x.stride(0), w.stride(0), n_out,
                                                  dt, EPI[epi], tile, self._stream()))
         else:
@@ -127,4 +133,24 @@ class HipDense:
         I = gu2.shape[1] // 2
         out = torch.empty((gu2.shape[0], I), dtype=gu.dtype, device=gu.device)
         _lib.check(self.lib.d3d_swiglu(_p(gu2), _p(out), gu2.shape[0], I, 0 if gu.dtype == torch.bfloat16 else 1, self._stream()))
+        return out
+
+    def set_attention(self, qkv, set_off, n_sets, n_heads, max_len, q_rows=0):
+        """qkv (T, 3*H*64) f32 packed sets -> (T, H*64) f32 (rows outside the queried range are zero)."""
+        out = torch.zeros((qkv.shape[0], n_heads * 64), dtype=torch.float32, device=qkv.device)
+        _lib.check(self.lib.d3d_set_attention(_p(qkv), _p(set_off), n_sets, n_heads, max_len, q_rows, _p(out), self._stream()))
+        return out
+
+    @staticmethod
+    def attention_ok(qkv, hd):
+        return qkv.dtype in (torch.bfloat16, torch.float16) and hd in (64, 96) and qkv.is_contiguous()
+
+    def attention_qkv(self, qkv, n_heads, causal, seq_len=None):
+        """qkv (B,S,3H,hd) contiguous fused projection -> (B,S,H,hd): flash attention straight off the projection buffer."""
+        B, S, Ht, hd = qkv.shape
+        out = torch.empty((B, S, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
+        vt = torch.empty((B, n_heads, hd, (S + 63) // 64 * 64), dtype=qkv.dtype, device=qkv.device)     # pre-transposed V workspace
+        _lib.check(self.lib.d3d_flash_attention(_p(qkv), _p(out), _p(vt), B, S, n_heads, hd, Ht * hd, S * Ht * hd, 0, n_heads, 2 * n_heads,
+                                                1 if causal else 0, S if seq_len is None else seq_len,
+                                                0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
         return out

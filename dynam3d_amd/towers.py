@@ -145,8 +145,8 @@ class _VitTrunk:
         B, L, W = x.shape
         for blk in self.blocks[:n_layers]:
             h = D.layer_norm(x, blk["ln1_w"], blk["ln1_b"], 1e-5)
-            qkv = D.linear(h.view(B * L, W), blk["qkv_w"], blk["qkv_b"]).view(B, L, 3, c.heads, W // c.heads)
-            a = D.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal=False)         # (B,L,H,hd)
+            qkv = D.linear(h.view(B * L, W), blk["qkv_w"], blk["qkv_b"]).view(B, L, 3 * c.heads, W // c.heads)
+            a = D.attention_qkv(qkv, c.heads, causal=False)                                    # (B,L,H,hd)
             x = D.linear(a.reshape(B * L, W), blk["out_w"], blk["out_b"], residual=x.view(B * L, W)).view(B, L, W)
             h = D.layer_norm(x, blk["ln2_w"], blk["ln2_b"], 1e-5)
             h = D.linear(h.view(B * L, W), blk["fc1_w"], blk["fc1_b"], act="quick_gelu")
@@ -266,8 +266,11 @@ class Phi3Decoder:
             h = D.rms_norm(x, L["n1"], c.rms_eps)
             qkv = D.linear(h.view(B * S, Hd), L["qkv_w"], None).view(B, S, c.heads + 2 * c.kv_heads, c.head_dim)
             qkv = D.rope_qk_(qkv, c.heads + c.kv_heads, cos, sin)
-            q, k, v = qkv[:, :, :c.heads], qkv[:, :, c.heads:c.heads + c.kv_heads], qkv[:, :, c.heads + c.kv_heads:]
-            a = D.attention(q, k, v, causal=True)
+            if c.kv_heads == c.heads:
+                a = D.attention_qkv(qkv, c.heads, causal=True)
+            else:
+                q, k, v = qkv[:, :, :c.heads], qkv[:, :, c.heads:c.heads + c.kv_heads], qkv[:, :, c.heads + c.kv_heads:]
+                a = D.attention(q, k, v, causal=True)
             x = D.linear(a.reshape(B * S, c.heads * c.head_dim), L["o_w"], None, residual=x.view(B * S, Hd)).view(B, S, Hd)
             h = D.rms_norm(x, L["n2"], c.rms_eps)
             with TIMER.range("phi3.gate_up_proj"):

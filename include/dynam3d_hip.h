@@ -180,6 +180,18 @@ int32_t d3d_rope_inplace(void* qkv_d, const float* cos_d, const float* sin_d, in
                          int32_t head_dim, int64_t ld, int32_t dtype, void* stream);
 /* out[m,i] = up * silu(gate) for a plain [gate(I) | up(I)] projection output */
 int32_t d3d_swiglu(const void* gate_up_d, void* out_d, int64_t rows, int32_t I, int32_t dtype, void* stream);
+/* fused (flash) self-attention forward over a fused QKV projection buffer (clip/model.py:171-183 MultiheadAttention,
+ * HF CLIP / Phi-3 attention): qkv (B,S,Htot,hd) 16-bit, q/k/v heads start at q_off/k_off/v_off; strides in elements;
+ * out (B,S,H,hd); hd in {64,96}; keys >= seq_len are masked; causal = lower-triangular. */
+int32_t d3d_flash_attention(const void* qkv_d, void* out_d, void* vt_scratch_d /* (B,H,hd,ceil64(S)) 16-bit */, int32_t B, int32_t S, int32_t H,
+                            int32_t head_dim, int64_t row_stride,
+                            int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
+                            int32_t dtype, void* stream);
+/* self-attention inside packed variable-length token sets (set encoders VLN-FF:134-155): float32, head_dim 64.
+ * qkv (T, 3*H*64) = [q|k|v]; set g = tokens [set_off[g], set_off[g+1]); q_rows > 0 restricts the queries to the
+ * first q_rows rows of every set (1 = CLS only).  out (T, H*64); rows that are not queried are left untouched. */
+int32_t d3d_set_attention(const float* qkv_d, const int32_t* set_off_d, int32_t n_sets, int32_t n_heads, int32_t max_len,
+                          int32_t q_rows, float* out_d, void* stream);
 /* a3 front-end (resnet_encoders.py:267-271): uint8 HWC -> bicubic SxS (rounded back to uint8) -> /255 -> normalise, f32 CHW */
 int32_t d3d_resize_normalize(const uint8_t* rgb_d, float* out_d, int32_t B, int32_t H, int32_t W, int32_t S,
                              const float* mean3_h, const float* std3_h, void* stream);

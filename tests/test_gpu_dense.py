@@ -85,3 +85,44 @@ def test_resize_normalize_matches_torch_bicubic(hd):
         diff = (got - exp).abs()
         assert float(diff.max()) <= 1.0 / 255 / min(CLIP_STD) + 1e-5
         assert float((diff > 1e-5).float().mean()) < 2e-3
+
+
+def test_set_attention_varlen(hd):
+    """d3d_set_attention (fp32 varlen self-attention inside packed sets) vs a per-set torch reference."""
+    torch.manual_seed(3)
+    H, lens = 12, [1, 37, 2, 64, 65, 300, 5]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(off[-1])
+    qkv = torch.randn(T, 3 * H * 64, device="cuda")
+    set_off = torch.from_numpy(off).cuda()
+    out = hd.set_attention(qkv, set_off, len(lens), H, max(lens))
+    cls = hd.set_attention(qkv, set_off, len(lens), H, max(lens), q_rows=1)
+    for g, L in enumerate(lens):
+        blk = qkv[off[g]:off[g + 1]].view(L, 3, H, 64)
+        q, k, v = (blk[:, j].transpose(0, 1) for j in range(3))
+        ref = F.scaled_dot_product_attention(q[None], k[None], v[None])[0].transpose(0, 1).reshape(L, H * 64)
+        assert torch.allclose(out[off[g]:off[g + 1]], ref, atol=2e-5, rtol=1e-4)
+        assert torch.allclose(cls[off[g]], ref[0], atol=2e-5, rtol=1e-4)
+        if L > 1:
+            assert float(cls[off[g] + 1:off[g + 1]].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 4e-3), (torch.float16, 6e-4)])
+def test_flash_attention_vs_fp32_reference(hd, dt, tol):
+    """d3d_flash_attention (head_dim 64/96, causal/full, ragged S, masked tail) vs float32 SDPA on the same 16-bit inputs."""
+    torch.manual_seed(4)
+    for (B, H, S, d, causal) in [(2, 3, 577, 64, False), (2, 4, 900, 96, True), (1, 2, 130, 96, True), (3, 2, 64, 64, True), (1, 1, 1, 96, True), (2, 2, 333, 96, False)]:
+        qkv = (torch.randn(B, S, 3 * H, d, device="cuda") * 1.5).to(dt)
+        qkv[:, :, H:2 * H] += 0.5                                  # asymmetric q/k
+        q, k, v = (qkv[:, :, i * H:(i + 1) * H].transpose(1, 2).float() for i in range(3))
+        ref = F.scaled_dot_product_attention(q, k, v, is_causal=causal).transpose(1, 2)
+        got = hd.attention_qkv(qkv, H, causal).float()
+        assert got.shape == ref.shape
+        assert rel(got, ref) < tol, (B, H, S, d, causal, rel(got, ref))
+    # a spike that forces the deferred-max rescale path (one key dominating late in the sequence)
+    B, H, S, d = 1, 1, 256, 96
+    qkv = (torch.randn(B, S, 3 * H, d, device="cuda") * 0.3).to(dt)
+    qkv[0, 200, 1] = qkv[0, 255, 0] * 40                            # k[200] aligned with q[255] -> huge score at a late tile
+    q, k, v = (qkv[:, :, i * H:(i + 1) * H].transpose(1, 2).float() for i in range(3))
+    ref = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2)
+    assert rel(hd.attention_qkv(qkv, H, True).float(), ref) < tol
