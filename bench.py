@@ -149,13 +149,21 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         fl = step_flops(cfg, lengths_seen[-1], B)
-        S_pad = max(lengths_seen[-1])
+        rows_gemm = getattr(net.llm, "last_packed_rows", None) or B * max(lengths_seen[-1])   # rows the GEMM actually processes
         tsum = TIMER.summary()
         n_gu, ms_gu = tsum.get("phi3.gate_up_proj", (0, float("nan")))
         l = cfg.llm
-        gu_flops = 2.0 * B * S_pad * l.hidden * 2 * l.mlp
+        gu_flops = 2.0 * sum(lengths_seen[-1]) * l.hidden * 2 * l.mlp                     # ALGORITHMIC: real tokens only
         achieved = gu_flops / (ms_gu * 1e-3) / 1e12 if n_gu else float("nan")
         st = net.feature_fields.state
+        traffic, traffic_note = None, None
+        pj = os.path.join(ROOT, "profiles", "r01_pmc_gate_up.json")
+        if os.path.isfile(pj) and dict(D.BACKEND)["linear"] == "hip":
+            # HBM bytes per launch of this kernel from the rocprofv3 PMC passes committed under profiles/ (same kernel, M=7168):
+            # 2*FETCH_SIZE + WRITE_SIZE (FETCH_SIZE counts 128-B requests at 64 B on gfx950, MI355X_MICROARCH.md); scaled by rows.
+            pm = json.load(open(pj))
+            traffic = int(pm["hbm_bytes_per_launch"] * rows_gemm / 7168.0)
+            traffic_note = "from profiles/r01_pmc_gate_up.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), scaled by launched rows"
         out = {
             "metric": "nav steps/sec (RGB-D obs->action logits) at batch=8", "value": round(B * a.steps * a.gpus / dt, 3), "unit": "env-steps/s",
             "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
@@ -166,8 +174,8 @@ def main():
                        "instances_per_env": st.count(0, st.LIVE), "clip_dtype": str(cfg.clip_dtype), "llm_dtype": str(cfg.llava_dtype),
                        "token_builder_dtype": "float32", "parallelism": f"episode-parallel x{a.gpus} (no data-path collective)",
                        "dense_backend": dict(D.BACKEND)},
-            "roofline": {"bound": "mfma", "kernel": "phi3.gate_up_proj GEMM (B*S x 3072 x 16384, bf16)", "achieved": round(achieved, 1),
-                         "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": "phi3.gate_up_proj GEMM + fused SwiGLU (sum(S_b) x 3072 x 16384, bf16)", "gemm_rows_launched": rows_gemm, "real_tokens": sum(lengths_seen[-1]), "achieved": round(achieved, 1),
+                         "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "launches_timed": n_gu, "avg_launch_ms": round(ms_gu, 4),
                          "step_total_tflop": round(fl["total"] / 1e12, 2), "step_frac_of_peak": round(fl["total"] / (ms * 1e-3) / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4),
                          "step_flop_split_tflop": {k: round(v / 1e12, 3) for k, v in fl.items() if k != "total"}},

@@ -56,11 +56,15 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 template <int HD>
 __global__ void __launch_bounds__(256)
 k_transpose_v(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ vt, int S, int Sp, int H, int64_t row_stride, int64_t batch_stride,
-              int v_off) {
+              int v_off, const int32_t* __restrict__ cu) {
     constexpr int CH = HD / 8;
     __shared__ uint16_t tile[HD][64 + 2];
     const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const uint16_t* Vp = qkv + (int64_t)b * batch_stride + (int64_t)(v_off + h) * HD;
+    if (cu) {                                   // packed batch: sequence b = rows [cu[b], cu[b+1])
+        S = cu[b + 1] - cu[b];
+        if (k0 >= S) return;
+    }
+    const uint16_t* Vp = qkv + (cu ? (int64_t)cu[b] * row_stride : (int64_t)b * batch_stride) + (int64_t)(v_off + h) * HD;
     for (int c = threadIdx.x; c < 64 * CH; c += 256) {
         const int key = c / CH, dc = c % CH;
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -83,7 +87,8 @@ k_transpose_v(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ vt, int S
 template <bool BF16, int HD, bool CAUSAL>
 __global__ void __launch_bounds__(NT, 2)          // 2 waves/SIMD = 2 workgroups per CU: keep VGPR+AGPR <= 256
 k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, int Sp, uint16_t* __restrict__ out, int S, int H,
-             int64_t row_stride /* elements between tokens */, int64_t batch_stride, int q_off, int k_off, float scale_log2e, int seq_len) {
+             int64_t row_stride /* elements between tokens */, int64_t batch_stride, int q_off, int k_off, float scale_log2e, int seq_len,
+             const int32_t* __restrict__ cu /* packed batch: (B+1) row offsets, or null */) {
     // K rows are padded to a power-of-two number of 16-byte chunks and XOR-swizzled (chunk ^= row & (KCH-1)): every
     // ds_read_b128 lane group (which mixes two k-groups, e.g. lanes {0-3,12-15,20-27}) then hits 16 distinct slots.
     constexpr int KCH = HD == 96 ? 16 : 8;   // chunk positions per LDS row
@@ -100,7 +105,15 @@ k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, 
     // causal: late query blocks have the most key tiles -> dispatch them first so the short ones fill the tail
     const int qb = CAUSAL ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int q0 = qb * BQ, qw = q0 + wave * 32;
+    int64_t row0 = (int64_t)b * S;                         // first output row of this sequence
     const uint16_t* base = qkv + (int64_t)b * batch_stride;
+    if (cu) {
+        row0 = cu[b];
+        S = cu[b + 1] - cu[b];
+        seq_len = S;
+        if (q0 >= S) return;                               // (uniform) query block beyond this sequence
+        base = qkv + row0 * row_stride;
+    }
     const uint16_t* Qp = base + (int64_t)(q_off + h) * HD;
     const uint16_t* Kp = base + (int64_t)(k_off + h) * HD;
     const uint16_t* Vtp = vt + (((int64_t)b * H + h) * HD) * Sp;          // (hd, Sp) key-major
@@ -270,7 +283,7 @@ k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, 
         const int q = qw + qt * 16 + fi;
         if (q >= S) continue;
         const float inv = 1.0f / l_i[qt];
-        uint16_t* op = out + (((int64_t)b * S + q) * H + h) * HD;
+        uint16_t* op = out + ((row0 + q) * H + h) * HD;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             uint2 o;
@@ -289,9 +302,11 @@ extern "C" {
 // at [k_off, ..), v heads at [v_off, ..); token stride = row_stride elements, batch stride = batch_stride elements.
 // out: (B, S, H, hd) contiguous.  seq_len = number of valid keys (<= S).  dtype 0 = bf16, 1 = fp16; hd in {64, 96}.
 // vt_scratch: caller-provided (B, H, hd, Sp) 16-bit workspace, Sp = S rounded up to 64 (the pre-transposed V).
+// cu_seqlens (optional, device, B+1 ints): PACKED batch -- sequence b occupies rows [cu[b], cu[b+1]) of qkv/out, S is then the
+// longest sequence (grid size) and batch_stride / seq_len are ignored.
 int32_t d3d_flash_attention(const void* qkv, void* out, void* vt_scratch, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride,
                             int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
-                            int32_t dtype, void* stream) {
+                            const int32_t* cu_seqlens, int32_t dtype, void* stream) {
     if (B <= 0 || S <= 0) return D3D_OK;
     if ((head_dim != 64 && head_dim != 96) || (row_stride & 7) || (batch_stride & 7)) {
         d3d_set_error_("d3d_flash_attention: head_dim must be 64 or 96; strides multiples of 8 elements");
@@ -304,10 +319,10 @@ int32_t d3d_flash_attention(const void* qkv, void* out, void* vt_scratch, int32_
     uint16_t* o = (uint16_t*)out;
     uint16_t* vt = (uint16_t*)vt_scratch;
     dim3 tg(Sp / 64, H, B);
-    if (head_dim == 96) hipLaunchKernelGGL(k_transpose_v<96>, tg, dim3(256), 0, s, q, vt, S, Sp, H, row_stride, batch_stride, v_off);
-    else hipLaunchKernelGGL(k_transpose_v<64>, tg, dim3(256), 0, s, q, vt, S, Sp, H, row_stride, batch_stride, v_off);
+    if (head_dim == 96) hipLaunchKernelGGL(k_transpose_v<96>, tg, dim3(256), 0, s, q, vt, S, Sp, H, row_stride, batch_stride, v_off, cu_seqlens);
+    else hipLaunchKernelGGL(k_transpose_v<64>, tg, dim3(256), 0, s, q, vt, S, Sp, H, row_stride, batch_stride, v_off, cu_seqlens);
     dim3 grid((S + BQ - 1) / BQ, H, B), block(NT);
-#define D3D_FA(BF, HDV, CA) hipLaunchKernelGGL((k_flash_attn<BF, HDV, CA>), grid, block, 0, s, q, vt, Sp, o, S, H, row_stride, batch_stride, q_off, k_off, sl2, seq_len)
+#define D3D_FA(BF, HDV, CA) hipLaunchKernelGGL((k_flash_attn<BF, HDV, CA>), grid, block, 0, s, q, vt, Sp, o, S, H, row_stride, batch_stride, q_off, k_off, sl2, seq_len, cu_seqlens)
     if (dtype == 0) {
         if (head_dim == 96) { if (causal) D3D_FA(true, 96, true); else D3D_FA(true, 96, false); }
         else { if (causal) D3D_FA(true, 64, true); else D3D_FA(true, 64, false); }

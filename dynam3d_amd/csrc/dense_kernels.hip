@@ -110,7 +110,7 @@ k_norm(const uint16_t* __restrict__ x, const float* __restrict__ w, const float*
 // (q heads then k heads are contiguous in Phi-3's qkv_proj output).  pos = row % S.
 template <bool BF16>
 __global__ void k_rope(uint16_t* __restrict__ qkv, const float* __restrict__ cos_t, const float* __restrict__ sin_t, int rows,
-                       int S, int n_rot_heads, int hd, int64_t ld) {
+                       int S, int n_rot_heads, int hd, int64_t ld, const int32_t* __restrict__ pos_of_row) {
     // one thread = 8 consecutive rotation pairs of one head: two 16-byte loads / stores (head_dim/2 % 8 == 0)
     const int half = hd >> 1, cpb = half >> 3;                    // chunks of 8 pairs per head
     const int per_row = n_rot_heads * cpb;
@@ -118,7 +118,7 @@ __global__ void k_rope(uint16_t* __restrict__ qkv, const float* __restrict__ cos
     if (i >= (int64_t)rows * per_row) return;
     const int row = (int)(i / per_row), r = (int)(i % per_row);
     const int h = r / cpb, p = (r % cpb) * 8;
-    const int pos = row % S;
+    const int pos = pos_of_row ? pos_of_row[row] : row % S;      // packed (varlen) batches carry an explicit position per row
     uint16_t* base = qkv + (int64_t)row * ld + h * hd + p;
     const uint4 a = *reinterpret_cast<const uint4*>(base), b = *reinterpret_cast<const uint4*>(base + half);
     const uint16_t* ah = reinterpret_cast<const uint16_t*>(&a);
@@ -311,7 +311,7 @@ int32_t d3d_norm(const void* x, const float* w, const float* b, void* y, int32_t
 }
 
 int32_t d3d_rope_inplace(void* qkv, const float* cos_t, const float* sin_t, int32_t rows, int32_t S, int32_t n_rot_heads,
-                         int32_t head_dim, int64_t ld, int32_t dtype, void* stream) {
+                         int32_t head_dim, int64_t ld, const int32_t* pos_of_row, int32_t dtype, void* stream) {
     if (rows <= 0) return D3D_OK;
     if ((head_dim / 2) % 8 != 0 || (ld & 7)) {
         d3d_set_error_("d3d_rope_inplace: head_dim/2 and ld must be multiples of 8");
@@ -320,9 +320,9 @@ int32_t d3d_rope_inplace(void* qkv, const float* cos_t, const float* sin_t, int3
     const int64_t n = (int64_t)rows * n_rot_heads * (head_dim / 16);
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (dtype == 0)
-        hipLaunchKernelGGL(k_rope<true>, grid, block, 0, (hipStream_t)stream, (uint16_t*)qkv, cos_t, sin_t, rows, S, n_rot_heads, head_dim, ld);
+        hipLaunchKernelGGL(k_rope<true>, grid, block, 0, (hipStream_t)stream, (uint16_t*)qkv, cos_t, sin_t, rows, S, n_rot_heads, head_dim, ld, pos_of_row);
     else
-        hipLaunchKernelGGL(k_rope<false>, grid, block, 0, (hipStream_t)stream, (uint16_t*)qkv, cos_t, sin_t, rows, S, n_rot_heads, head_dim, ld);
+        hipLaunchKernelGGL(k_rope<false>, grid, block, 0, (hipStream_t)stream, (uint16_t*)qkv, cos_t, sin_t, rows, S, n_rot_heads, head_dim, ld, pos_of_row);
     D3D_LAUNCH_CHECK();
 }
 

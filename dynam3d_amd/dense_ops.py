@@ -95,6 +95,21 @@ def attention_qkv(qkv: torch.Tensor, n_heads: int, causal: bool) -> torch.Tensor
     return attention(qkv[:, :, :n_heads], qkv[:, :, n_heads:2 * n_heads], qkv[:, :, 2 * n_heads:], causal)
 
 
+def packed_ok(dtype, head_dim: int) -> bool:
+    """True when the packed (variable-length, no padding) decoder path is available: HIP rope + flash attention."""
+    return (BACKEND["attention"] == "hip" and BACKEND["rope"] == "hip" and dtype in (torch.bfloat16, torch.float16)
+            and head_dim in (64, 96) and (head_dim // 2) % 8 == 0)
+
+
+def rope_packed_(qkv2d: torch.Tensor, n_rot_heads: int, head_dim: int, cos, sin, pos: torch.Tensor):
+    _hip.rope_inplace(qkv2d, cos, sin, 1, n_rot_heads, head_dim, pos)
+    return qkv2d
+
+
+def attention_packed(qkv3: torch.Tensor, n_heads: int, causal: bool, cu_seqlens: torch.Tensor, n_seq: int, max_len: int):
+    return _hip.attention_packed(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len)
+
+
 def rope_qk_(qkv: torch.Tensor, n_rot_heads: int, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
     """Rotate the first `n_rot_heads` heads (q heads then k heads) of the fused projection qkv (B,S,Htot,hd);
     in place on the HIP backend (one pass over q,k instead of slice/float/cat round trips)."""

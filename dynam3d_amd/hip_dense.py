@@ -14,9 +14,9 @@ EPI = dict(none=0, bias=1, bias_quick_gelu=2, bias_gelu=3, res=4, bias_res=5, sw
 _lib.register("d3d_gemm_nt", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, vp])
 _lib.register("d3d_gemm_nt_tile", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32, vp])
 _lib.register("d3d_norm", [vp, vp, vp, vp, i32, i32, i64, i64, f32, i32, i32, vp])
-_lib.register("d3d_rope_inplace", [vp, vp, vp, i32, i32, i32, i32, i64, i32, vp])
+_lib.register("d3d_rope_inplace", [vp, vp, vp, i32, i32, i32, i32, i64, vp, i32, vp])
 _lib.register("d3d_set_attention", [vp, vp, i32, i32, i32, i32, vp, vp])
-_lib.register("d3d_flash_attention", [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, i32, vp])
+_lib.register("d3d_flash_attention", [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp])
 _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
 _lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
 
@@ -114,9 +114,9 @@ class HipDense:
     def rms_norm(self, x, w, eps):
         return self._norm(x, w, None, eps, True)
 
-    def rope_inplace(self, qkv2d, cos, sin, S, n_rot_heads, hd):
-        """qkv2d (rows, >= n_rot_heads*hd) bf16/fp16, rotated in place; position = row % S."""
-        _lib.check(self.lib.d3d_rope_inplace(_p(qkv2d), _p(cos), _p(sin), qkv2d.shape[0], S, n_rot_heads, hd, qkv2d.stride(0),
+    def rope_inplace(self, qkv2d, cos, sin, S, n_rot_heads, hd, pos=None):
+        """qkv2d (rows, >= n_rot_heads*hd) bf16/fp16, rotated in place; position = pos[row] if given else row % S."""
+        _lib.check(self.lib.d3d_rope_inplace(_p(qkv2d), _p(cos), _p(sin), qkv2d.shape[0], S, n_rot_heads, hd, qkv2d.stride(0), _p(pos),
                                              0 if qkv2d.dtype == torch.bfloat16 else 1, self._stream()))
 
     def resize_normalize(self, rgb_u8, size, mean, std):
@@ -151,6 +151,16 @@ class HipDense:
         out = torch.empty((B, S, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
         vt = torch.empty((B, n_heads, hd, (S + 63) // 64 * 64), dtype=qkv.dtype, device=qkv.device)     # pre-transposed V workspace
         _lib.check(self.lib.d3d_flash_attention(_p(qkv), _p(out), _p(vt), B, S, n_heads, hd, Ht * hd, S * Ht * hd, 0, n_heads, 2 * n_heads,
-                                                1 if causal else 0, S if seq_len is None else seq_len,
+                                                1 if causal else 0, S if seq_len is None else seq_len, None,
                                                 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
+        return out
+
+    def attention_packed(self, qkv, n_heads, causal, cu_seqlens, n_seq, max_len):
+        """PACKED variable-length batch: qkv (T, 3H, hd) rows of sequence b = [cu[b], cu[b+1]) -> (T, H, hd).  Rows beyond
+        cu[-1] (padding of the packed buffer) are left untouched."""
+        T, Ht, hd = qkv.shape
+        out = torch.zeros((T, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
+        vt = torch.empty((n_seq, n_heads, hd, (max_len + 63) // 64 * 64), dtype=qkv.dtype, device=qkv.device)
+        _lib.check(self.lib.d3d_flash_attention(_p(qkv), _p(out), _p(vt), n_seq, max_len, n_heads, hd, Ht * hd, 0, 0, n_heads, 2 * n_heads,
+                                                1 if causal else 0, max_len, _p(cu_seqlens), 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
         return out

@@ -152,7 +152,7 @@ class Dynam3D_VLN:
 
     @torch.no_grad()
     def build_inputs(self, observations, instructions, agent_positions, agent_heading_angles, depth_scale=(0.0, 10.0),
-                     delete_old_features=True, num_of_views=1, patch_segm=None):
+                     delete_old_features=True, num_of_views=1, patch_segm=None, return_rows=False):
         """Everything up to the LM: returns (inputs_embeds (B,S,3072) right-padded, lengths (B,))  (VLN-POL:331-461)."""
         ff, V = self.feature_fields, num_of_views
         B = ff.batch_size
@@ -206,20 +206,22 @@ class Dynam3D_VLN:
             row = torch.cat([head_e, patch_tok[b], inst_tok[io[b]:io[b + 1]], zone_tok[zo[b]:zo[b + 1]], te], 0)   # VLN-POL:456
             rows.append(row)
             lengths.append(row.shape[0])
+        self.last_lengths = lengths
+        self.last_counts = dict(Ni=ni, Nz=nz)
+        if return_rows:
+            return rows, lengths
         S = max(lengths)
         embeds = torch.zeros((B, S, self.cfg.llm.hidden), dtype=self.cfg.llava_dtype, device=self.device)
         for b, r in enumerate(rows):
             embeds[b, :r.shape[0]] = r.to(self.cfg.llava_dtype)
-        self.last_lengths = lengths
-        self.last_counts = dict(Ni=ni, Nz=nz)
         return embeds, torch.tensor(lengths, device=self.device)
 
     @torch.no_grad()
     def forward_logits(self, observations, instructions, agent_positions, agent_heading_angles, depth_scale=(0.0, 10.0),
                        gt_text=None, delete_old_features=True, num_of_views=1, is_train=False, patch_segm=None) -> torch.Tensor:
-        embeds, lengths = self.build_inputs(observations, instructions, agent_positions, agent_heading_angles, depth_scale,
-                                            delete_old_features, num_of_views, patch_segm)
-        return self.llm.prefill_logits(embeds, lengths)
+        rows, _ = self.build_inputs(observations, instructions, agent_positions, agent_heading_angles, depth_scale,
+                                    delete_old_features, num_of_views, patch_segm, return_rows=True)
+        return self.llm.prefill_logits_rows(rows)
 
     @torch.no_grad()
     def forward(self, observations, instructions, agent_positions, agent_heading_angles, depth_scale=(0.0, 10.0), gt_text=None,

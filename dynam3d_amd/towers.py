@@ -255,6 +255,50 @@ class Phi3Decoder:
         return self._rope_cache[S]
 
     @torch.no_grad()
+    def prefill_logits_rows(self, rows) -> torch.Tensor:
+        """rows: list of B tensors (S_b, hidden) -- the per-environment prompts.  With the HIP backend the batch is PACKED
+        (no padding: sum(S_b) tokens, rounded up to a multiple of 256 rows so every GEMM is whole 256-row tiles) and
+        attention / RoPE work off per-sequence offsets; otherwise it is right-padded and sent to `prefill_logits`."""
+        c = self.cfg
+        lens = [int(r.shape[0]) for r in rows]
+        B = len(rows)
+        if not (D.packed_ok(self.dtype, c.head_dim) and c.kv_heads == c.heads and rows[0].is_cuda):
+            S = max(lens)
+            emb = torch.zeros((B, S, c.hidden), dtype=self.dtype, device=self.device)
+            for b, r in enumerate(rows):
+                emb[b, :lens[b]] = r.to(self.dtype)
+            return self.prefill_logits(emb, torch.tensor(lens, device=self.device))
+        T = sum(lens)
+        Tp = (T + 255) // 256 * 256
+        x = torch.zeros((Tp, c.hidden), dtype=self.dtype, device=self.device)
+        torch.cat([r.to(self.dtype) for r in rows], 0, out=x[:T])
+        cu_h = [0]
+        for n in lens:
+            cu_h.append(cu_h[-1] + n)
+        cu = torch.tensor(cu_h, dtype=torch.int32, device=self.device)
+        pos_h = torch.zeros(Tp, dtype=torch.int32)
+        for b, n in enumerate(lens):
+            pos_h[cu_h[b]:cu_h[b + 1]] = torch.arange(n, dtype=torch.int32)
+        pos = pos_h.to(self.device, non_blocking=True)
+        max_len = max(lens)
+        cos, sin = self._rope(max_len)
+        Ht = c.heads + 2 * c.kv_heads
+        for L in self.layers:
+            h = D.rms_norm(x, L["n1"], c.rms_eps)
+            qkv = D.linear(h, L["qkv_w"], None)
+            D.rope_packed_(qkv, c.heads + c.kv_heads, c.head_dim, cos, sin, pos)
+            a = D.attention_packed(qkv.view(Tp, Ht, c.head_dim), c.heads, True, cu, B, max_len)
+            x = D.linear(a.view(Tp, c.heads * c.head_dim), L["o_w"], None, residual=x)
+            h = D.rms_norm(x, L["n2"], c.rms_eps)
+            with TIMER.range("phi3.gate_up_proj"):
+                act = D.linear_swiglu(h, L["gu_w"], self.interleave_gu)
+            x = D.linear(act, L["down_w"], None, residual=x)
+        self.last_packed_rows = Tp
+        last = x[(cu[1:] - 1).long()]
+        last = D.rms_norm(last, self.norm_w, c.rms_eps)
+        return D.linear(last, self.lm_head_w, None).float()
+
+    @torch.no_grad()
     def prefill_logits(self, inputs_embeds: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
         """inputs_embeds (B,S,3072) right-padded, lengths (B,) real lengths -> logits (B,vocab) float32 at the last
         real position of each row.  Causal attention makes right padding invisible to real tokens."""

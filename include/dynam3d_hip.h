@@ -177,7 +177,8 @@ int32_t d3d_norm(const void* x_d, const float* w_d, const float* b_d, void* y_d,
                  int64_t ldy, float eps, int32_t rms, int32_t dtype, void* stream);
 /* in-place half-split rotary embedding on the first n_rot_heads heads of each fused-QKV row; position = row % S */
 int32_t d3d_rope_inplace(void* qkv_d, const float* cos_d, const float* sin_d, int32_t rows, int32_t S, int32_t n_rot_heads,
-                         int32_t head_dim, int64_t ld, int32_t dtype, void* stream);
+                         int32_t head_dim, int64_t ld, const int32_t* pos_of_row_d /* optional: explicit position per row */,
+                         int32_t dtype, void* stream);
 /* out[m,i] = up * silu(gate) for a plain [gate(I) | up(I)] projection output */
 int32_t d3d_swiglu(const void* gate_up_d, void* out_d, int64_t rows, int32_t I, int32_t dtype, void* stream);
 /* fused (flash) self-attention forward over a fused QKV projection buffer (clip/model.py:171-183 MultiheadAttention,
@@ -186,7 +187,7 @@ int32_t d3d_swiglu(const void* gate_up_d, void* out_d, int64_t rows, int32_t I, 
 int32_t d3d_flash_attention(const void* qkv_d, void* out_d, void* vt_scratch_d /* (B,H,hd,ceil64(S)) 16-bit */, int32_t B, int32_t S, int32_t H,
                             int32_t head_dim, int64_t row_stride,
                             int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
-                            int32_t dtype, void* stream);
+                            const int32_t* cu_seqlens_d /* optional (B+1): packed variable-length batch */, int32_t dtype, void* stream);
 /* self-attention inside packed variable-length token sets (set encoders VLN-FF:134-155): float32, head_dim 64.
  * qkv (T, 3*H*64) = [q|k|v]; set g = tokens [set_off[g], set_off[g+1]); q_rows > 0 restricts the queries to the
  * first q_rows rows of every set (1 = CLS only).  out (T, H*64); rows that are not queried are left untouched. */
