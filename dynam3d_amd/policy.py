@@ -116,6 +116,7 @@ class Dynam3D_VLN:
         self.mlp_w = {k: sd[k].to(self.device, torch.float32).contiguous() for k, _ in prefix_param_spec(768, cfg.llm.hidden)}
         self.tokenizer = tokenizer or SyntheticTokenizer(cfg.llm.vocab)
         self.last_lengths = None
+        self._lowp_w = {}
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
@@ -131,12 +132,22 @@ class Dynam3D_VLN:
         d = depth.to(self.device)
         return self.ops.preprocess_depth(d.reshape(d.shape[0], d.shape[1], d.shape[2]), depth_scale[0], depth_scale[1]).view(d.shape)
 
-    def _mlp(self, x, name):
+    def _mlp(self, x, name, lowp=False):
+        """nn.Sequential(Linear, LayerNorm, GELU, Linear) (VLN-POL:83-111).  `lowp`: run the second (hidden x hidden) layer
+        as a 16-bit MFMA GEMM in the LM's dtype -- its result is added to LM-dtype features anyway (VLN-POL:453), and the
+        reference evaluates these layers under autocast."""
         import torch.nn.functional as F
         w = self.mlp_w
         h = F.linear(x, w[name + ".0.weight"], w[name + ".0.bias"])
-        h = F.layer_norm(h, (h.shape[-1],), w[name + ".1.weight"], w[name + ".1.bias"], 1e-5)
-        return F.linear(F.gelu(h), w[name + ".3.weight"], w[name + ".3.bias"])
+        h = F.gelu(F.layer_norm(h, (h.shape[-1],), w[name + ".1.weight"], w[name + ".1.bias"], 1e-5))
+        if lowp and x.is_cuda and self.cfg.llava_dtype != torch.float32:
+            dt = self.cfg.llava_dtype
+            key = name + ".3.weight." + str(dt)
+            if key not in self._lowp_w:
+                self._lowp_w[key] = (w[name + ".3.weight"].to(dt).contiguous(), w[name + ".3.bias"].to(dt).contiguous())
+            w3, b3 = self._lowp_w[key]
+            return D.linear(h.reshape(-1, h.shape[-1]).to(dt), w3, b3).view(*h.shape[:-1], -1)
+        return F.linear(h, w[name + ".3.weight"], w[name + ".3.bias"])
 
     def _depth24(self, depth, V, depth_scale):
         B = depth.shape[0]
@@ -179,7 +190,7 @@ class Dynam3D_VLN:
         env = ff.get_environment_features(agent_positions, agent_heading_angles)
         rel_x, rel_y, rel_z, direction, scale = ff.get_patch_3d_info(depth24.reshape(B * V, -1))
         info = torch.cat([rel_x, rel_y, rel_z, torch.sin(direction), torch.cos(direction), scale], dim=-1)   # VLN-POL:432
-        patch_pos = self._mlp(info, "patch_position_embedding")                               # (B*V,576,3072)
+        patch_pos = self._mlp(info, "patch_position_embedding", lowp=True)                    # (B*V,576,3072)
         ni = [int(t.shape[0]) for t in env["batch_instance_fts"]]
         nz = [int(t.shape[0]) for t in env["batch_zone_fts"]]
         ifts, irel = torch.cat(env["batch_instance_fts"]), torch.cat(env["batch_instance_relative_position"])

@@ -58,3 +58,17 @@ def test_phi3_packed_varlen_prefill_matches_oracle():
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
     assert rel(got, ref) < 3e-2 and rel(pad, ref) < 3e-2 and rel(got, pad) < 2e-2, (rel(got, ref), rel(pad, ref), rel(got, pad))
     assert np.array_equal(got.argmax(-1), ref.argmax(-1))
+
+
+def test_rollout_driver_pops_finished_episodes():
+    """Config-4 shaped driver on one rank: episodes of different length, pop() compaction, single metric gather."""
+    import dataclasses
+    from dynam3d_amd import dist as DD
+    from dynam3d_amd.policy import Dynam3D_VLN, synth_policy_weights
+    from dynam3d_amd.rollout import run_rollout
+    cfg = dataclasses.replace(SMALL, clip_dtype=torch.float16, llava_dtype=torch.bfloat16)
+    net = Dynam3D_VLN(cfg, synth_policy_weights(cfg, 0), device="cuda", batch_size=3, max_steps=8)
+    sums, n = run_rollout(net, 3, 5, seed=4, stop_token_mod=3)
+    assert n == 3 and net.feature_fields.batch_size == 0
+    res = DD.gather_metrics(sums, n, device="cuda")
+    assert res["episodes"] == 3.0 and 1.0 <= res["steps_taken"] <= 5.0

@@ -38,8 +38,8 @@ for step in range(3):
     fr = ep.next()
     obs = dict(rgb=torch.from_numpy(fr.rgb).to(dev), depth=torch.from_numpy(fr.depth).to(dev))
     pos, hd = [p.tolist() for p in fr.positions], list(fr.headings)
-    t0 = sync(); emb, L = net.build_inputs(obs, instr, pos, hd, patch_segm=fr.patch_segm); t1 = sync()
-    lo = net.llm.prefill_logits(emb, L); t2 = sync()
+    t0 = sync(); rows, L = net.build_inputs(obs, instr, pos, hd, patch_segm=fr.patch_segm, return_rows=True); t1 = sync()
+    lo = net.llm.prefill_logits_rows(rows); t2 = sync()
     acc.setdefault("build_inputs_total", []).append((t1 - t0) * 1e3); acc.setdefault("phi3_prefill", []).append((t2 - t1) * 1e3)
 for k, v in acc.items():
     print(f"{k:20s} {sum(v) / len(v):8.2f} ms   {['%.1f' % x for x in v]}")
