@@ -83,19 +83,26 @@ __device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-
 // In asm the DMA is invisible to that bookkeeping; the kernels below wait for it explicitly (counted in tiles)
 // and order it against the ds_reads with s_barrier.  M0 (LDS destination base) is saved/restored around the
 // statement (cdna_hip_programming.md 5.7).
+// Addressing: SGPR base (tile origin + K offset, advanced with scalar adds) + one loop-invariant 32-bit VGPR byte offset per
+// piece (row * ld + swizzled chunk), so issuing a tile costs no vector ALU work inside the K loop.
 template <int WAVES>
-__device__ __forceinline__ void stage_tile_dma(const uint16_t* __restrict__ g, int64_t ld, int row0, int rows_valid, int k0,
-                                               uint32_t lds_byte_addr, int wave, int lane) {
-    // wave w issues pieces w, w+WAVES, w+2*WAVES, w+3*WAVES  (4*WAVES pieces of 8 rows = 32*WAVES rows)
-    const uint16_t* src[4];
+struct TileLanes {
+    uint32_t off[4];     // wave w owns pieces w, w+WAVES, w+2*WAVES, w+3*WAVES  (4*WAVES pieces of 8 rows = 32*WAVES rows)
+    __device__ __forceinline__ void init(int64_t ld, int row0, int rows_valid, int wave, int lane) {
+        const int base_row = row0 < rows_valid ? row0 : rows_valid - 1;         // (offsets are relative to the clamped origin)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int r = (wave + p * WAVES) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (r & 7);
-        int gr = row0 + r;
-        gr = gr < rows_valid ? gr : rows_valid - 1;
-        src[p] = g + (int64_t)gr * ld + k0 + c * 8;
+        for (int p = 0; p < 4; ++p) {
+            const int r = (wave + p * WAVES) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            int gr = row0 + r;
+            gr = (gr < rows_valid ? gr : rows_valid - 1) - base_row;
+            off[p] = (uint32_t)(((int64_t)gr * ld + c * 8) * 2);
+        }
     }
+};
+
+template <int WAVES>
+__device__ __forceinline__ void stage_tile_dma(const TileLanes<WAVES>& tl, const uint16_t* __restrict__ base, uint32_t lds_byte_addr, int wave) {
     const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr + (uint32_t)wave * 1024u);
     uint32_t keep;
     constexpr int STEP = WAVES * 1024;
@@ -103,19 +110,19 @@ __device__ __forceinline__ void stage_tile_dma(const uint16_t* __restrict__ g, i
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %5\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, %7\n\t"
         "s_add_u32 m0, m0, %6\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, off\n\t"
+        "global_load_lds_dwordx4 %2, %7\n\t"
         "s_add_u32 m0, m0, %6\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, off\n\t"
+        "global_load_lds_dwordx4 %3, %7\n\t"
         "s_add_u32 m0, m0, %6\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %4, off\n\t"
+        "global_load_lds_dwordx4 %4, %7\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(dst), "i"(STEP)
+        : "v"(tl.off[0]), "v"(tl.off[1]), "v"(tl.off[2]), "v"(tl.off[3]), "s"(dst), "i"(STEP), "s"(base)
         : "memory");
 }
 
@@ -199,8 +206,13 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
     const int nk = K / BK;
     // LDS: buffer b -> A tile at smem + b*2*BM*BK, B tile right behind it
     const uint32_t lds0 = lds_addr_of(smem);
-    stage_tile_dma<4>(A, lda, row0, M, 0, lds0, wave, lane);
-    stage_tile_dma<4>(W, ldw, col0, N, 0, lds0 + BM * BK * 2, wave, lane);
+    TileLanes<4> ta, tw;
+    ta.init(lda, row0, M, wave, lane);
+    tw.init(ldw, col0, N, wave, lane);
+    const uint16_t* abase = A + (int64_t)row0 * lda;
+    const uint16_t* wbase = W + (int64_t)col0 * ldw;
+    stage_tile_dma<4>(ta, abase, lds0, wave);
+    stage_tile_dma<4>(tw, wbase, lds0 + BM * BK * 2, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -209,8 +221,8 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
         const int cur = t & 1;
         if (t + 1 < nk) {
             const uint32_t nxt = lds0 + (cur ^ 1) * (2 * BM * BK * 2);
-            stage_tile_dma<4>(A, lda, row0, M, (t + 1) * BK, nxt, wave, lane);
-            stage_tile_dma<4>(W, ldw, col0, N, (t + 1) * BK, nxt + BM * BK * 2, wave, lane);
+            stage_tile_dma<4>(ta, abase + (t + 1) * BK, nxt, wave);
+            stage_tile_dma<4>(tw, wbase + (t + 1) * BK, nxt + BM * BK * 2, wave);
         }
         const uint16_t* la = smem + cur * (2 * BM * BK);
         const uint16_t* lb = la + BM * BK;
@@ -264,8 +276,7 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
 // ================================================================================================
 constexpr int TM = 256, TN = 256, T_THREADS = 512;
 
-// DBG (timing experiments only, wrong results): 1 = no LDS-DMA inside the loop, 2 = DMA issued but never waited for
-template <bool BF16, int EPI, bool KFULL = false, int DBG = 0>
+template <bool BF16, int EPI, bool KFULL>
 __global__ void __launch_bounds__(T_THREADS, 2)
 k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* __restrict__ C,
               const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, int M, int N, int K, int64_t lda,
@@ -323,8 +334,13 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
 
     const int nk = K / BK;
     const uint32_t lds0 = lds_addr_of(smem);
-    stage_tile_dma<8>(A, lda, row0, M, 0, lds0, wave, lane);
-    stage_tile_dma<8>(W, ldw, col0, N, 0, lds0 + TM * BK * 2, wave, lane);
+    TileLanes<8> ta, tw;
+    ta.init(lda, row0, M, wave, lane);
+    tw.init(ldw, col0, N, wave, lane);
+    const uint16_t* abase = A + (int64_t)row0 * lda;
+    const uint16_t* wbase = W + (int64_t)col0 * ldw;
+    stage_tile_dma<8>(ta, abase, lds0, wave);
+    stage_tile_dma<8>(tw, wbase, lds0 + TM * BK * 2, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -334,22 +350,22 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     // group 0 drains its share at the end of its last step of the tile, group 1 (a step late) one step earlier.
     if (grp == 1) __builtin_amdgcn_s_barrier();
     for (int t = 0; t < nk; ++t) {
-        if (DBG != 1 && t + 1 < nk) {
+        if (t + 1 < nk) {
             const uint32_t nxt = lds0 + ((t + 1) & 1) * (BUF * 2);
-            stage_tile_dma<8>(A, lda, row0, M, (t + 1) * BK, nxt, wave, lane);
-            stage_tile_dma<8>(W, ldw, col0, N, (t + 1) * BK, nxt + TM * BK * 2, wave, lane);
+            stage_tile_dma<8>(ta, abase + (t + 1) * BK, nxt, wave);
+            stage_tile_dma<8>(tw, wbase + (t + 1) * BK, nxt + TM * BK * 2, wave);
         }
         if constexpr (KFULL) {
             LOAD(t, 0, 0);
             LOAD(t, 1, 1);
-            if (DBG == 0 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
             COMPUTE(0);
             COMPUTE(1);
             __builtin_amdgcn_s_setprio(0);
-            if (DBG == 0 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         } else {
             LOAD(t, 0, 0);
@@ -386,17 +402,17 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     }
 }
 
-template <bool BF16, int EPI, bool KFULL = false, int DBG = 0>
+template <bool BF16, int EPI, bool KFULL>
 int32_t launch256(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
                   int64_t ldw, int64_t ldc, hipStream_t s) {
     const int tm = (M + TM - 1) / TM, tn = N / TN;
     const size_t sh = 2 * 2 * TM * BK * sizeof(uint16_t);   // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, KFULL, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, KFULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL, DBG>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
+    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
                        (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn);
     D3D_LAUNCH_CHECK();
 }
@@ -433,7 +449,7 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
     const int64_t rows256 = (int64_t)(M / TM) * TM;
     const int64_t blocks256 = (rows256 / TM) * (N / TN);
     if (N % TN == 0 && blocks256 >= 768) {
-        int32_t rc = d3d_gemm_nt_tile(A, W, C, bias, residual, (int32_t)rows256, N, K, lda, ldw, ldc, dtype, epilogue, 256, stream);
+        int32_t rc = d3d_gemm_nt_tile(A, W, C, bias, residual, (int32_t)rows256, N, K, lda, ldw, ldc, dtype, epilogue, 257, stream);
         if (rc != D3D_OK || rows256 == M) return rc;
         const char* a8 = (const char*)A + rows256 * lda * 2;
         char* c8 = (char*)C + rows256 * ldc * 2;
@@ -446,8 +462,12 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
 int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream) {
     if (M <= 0) return D3D_OK;
+    if (tile != 128 && tile != 256 && tile != 257) {
+        d3d_set_error_("d3d_gemm_nt_tile: tile must be 128, 256 (K-half steps) or 257 (whole-K-tile steps)");
+        return D3D_EINVAL;
+    }
     if (tile >= 256 && N % TN != 0) {
-        d3d_set_error_("d3d_gemm_nt_tile: tile 256 needs N % 256 == 0");
+        d3d_set_error_("d3d_gemm_nt_tile: the 256 x 256 tile needs N % 256 == 0");
         return D3D_EINVAL;
     }
     if (N % BN != 0 || K % BK != 0 || (lda & 7) || (ldw & 7) || (ldc & 3)) {
@@ -457,15 +477,12 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
     hipStream_t s = (hipStream_t)stream;
 #define D3D_GEMM_CASE(E)                                                                                              \
     case E:                                                                                                           \
-        if (tile == 257 && dtype == 0 && (E == EPI_NONE || E == EPI_SWIGLU))                                          \
-            return launch256<true, E, true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);                       \
-        if (tile == 258 && dtype == 0 && E == EPI_NONE)                                                                \
-            return launch256<true, E, true, 1>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);                    \
-        if (tile == 259 && dtype == 0 && E == EPI_NONE)                                                                \
-            return launch256<true, E, true, 2>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);                    \
-        if (tile >= 256)                                                                                              \
-            return dtype == 0 ? launch256<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)                 \
-                              : launch256<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);               \
+        if (tile == 256)                                                                                              \
+            return dtype == 0 ? launch256<true, E, false>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)          \
+                              : launch256<false, E, false>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);        \
+        if (tile == 257)                                                                                              \
+            return dtype == 0 ? launch256<true, E, true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)           \
+                              : launch256<false, E, true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);         \
         return dtype == 0 ? launch<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)                        \
                           : launch<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);
     switch (epilogue) {

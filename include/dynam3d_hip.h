@@ -167,7 +167,8 @@ int32_t d3d_agent_frame_compact(const float* pool_pos_d, const float* pool_fts_d
 int32_t d3d_gemm_nt(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
                     int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
                     void* stream);
-/* same with an explicit tile (128 | 256); d3d_gemm_nt picks one (and splits the M remainder) itself.  epilogue 7 =
+/* same with an explicit tile: 128 = 128x128x64 (4 waves, 2 workgroups/CU), 256 / 257 = 256x256x64 staggered wave groups
+ * stepping K-halves / whole K tiles; d3d_gemm_nt picks one (and splits the M remainder) itself.  epilogue 7 =
  * LeakyReLU(0.01) for the tcnn CutlassMLP replacement. */
 int32_t d3d_gemm_nt_tile(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
                          int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,

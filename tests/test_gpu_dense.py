@@ -48,6 +48,31 @@ def test_gemm_epilogues_asymmetric(hd, dt, tol):
         assert rel(hd.linear(big[:, :K], w, None, None).float(), big[:, :K].float() @ w.float().t()) < tol
 
 
+@pytest.mark.parametrize("tile", [256, 257])
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
+def test_gemm_256_tile_kernels(hd, dt, tol, tile):
+    """The 256x256x64 staggered kernel forced explicitly in both step sizes (256 = K-half steps, 257 = whole-K-tile steps):
+    ragged M, one and many K tiles, every fused epilogue."""
+    from dynam3d_amd.hip_dense import HipDense, interleave_gate_up
+    torch.manual_seed(2)
+    try:
+        HipDense.TILE = tile
+        for M, N, K in ((300, 256, 64), (512, 512, 128), (1000, 768, 1024), (2304, 3072, 192)):
+            x = (torch.randn(M, K, device="cuda") * 0.7).to(dt)
+            w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
+            w[3] *= 4.0
+            x[:, 5] += 1.0
+            b = (torch.randn(N, device="cuda") * 0.3).to(dt)
+            r = torch.randn(M, N, device="cuda").to(dt)
+            y32 = x.float() @ w.float().t()
+            assert rel(hd.linear(x, w, None, None).float(), y32) < tol, (M, N, K, "none")
+            assert rel(hd.linear(x, w, b, "quick_gelu").float(), (lambda t: t * torch.sigmoid(1.702 * t))(y32 + b.float())) < tol, (M, N, K, "qgelu")
+            assert rel(hd.linear(x, w, b, None, r).float(), y32 + b.float() + r.float()) < tol, (M, N, K, "bias_res")
+            assert rel(hd.linear_swiglu(x, interleave_gate_up(w)).float(), y32[:, N // 2:] * F.silu(y32[:, :N // 2])) < tol, (M, N, K, "swiglu")
+    finally:
+        HipDense.TILE = 0
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
 def test_norms_rope_swiglu(hd, dt, tol):
     torch.manual_seed(2)
