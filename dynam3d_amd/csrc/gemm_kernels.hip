@@ -23,6 +23,9 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "../../include/dynam3d_hip.h"
 #include "d3d_common.h"
 
@@ -276,18 +279,33 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
 // ================================================================================================
 constexpr int TM = 256, TN = 256, T_THREADS = 512;
 
-template <bool BF16, int EPI, bool KFULL>
+// SPLIT: the grid is `dp_tiles` whole tiles (a multiple of the CU count: full rounds, data parallel) followed by the TAIL tiles
+// that would not fill a round, each cut into `splits` K-slices so that the partial last round lasts 1/splits of a tile
+// instead of a whole one.  Every slice writes its fp32 accumulators to the workspace, waits for its siblings (one counter per
+// tile) and then reduces + finishes ITS share of the tile, summing in slice order -- deterministic.
+template <bool BF16, int EPI, bool KFULL, bool SPLIT>
 __global__ void __launch_bounds__(T_THREADS, 2)
 k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* __restrict__ C,
               const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, int M, int N, int K, int64_t lda,
-              int64_t ldw, int64_t ldc, int tiles_m, int tiles_n) {
+              int64_t ldw, int64_t ldc, int tiles_m, int tiles_n, int dp_tiles, int splits, float* __restrict__ ws,
+              uint32_t* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2][A 256x64 | B 256x64]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwg = tiles_m * tiles_n;
+    const int nk = K / BK;
+    const int nwg = SPLIT ? dp_tiles : tiles_m * tiles_n;
     int wg = blockIdx.x;
-    {
+    int kb = 0, ke = nk, slice = 0, tail_idx = -1;
+    if (!SPLIT || wg < nwg) {
         const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    } else {
+        // tail: slice-major, so that the workgroups running side by side work on the same K range of neighbouring tiles
+        const int w = wg - dp_tiles, tail = tiles_m * tiles_n - dp_tiles;
+        slice = __builtin_amdgcn_readfirstlane(w / tail);
+        tail_idx = __builtin_amdgcn_readfirstlane(w - slice * tail);
+        wg = dp_tiles + tail_idx;
+        kb = __builtin_amdgcn_readfirstlane(slice * nk / splits);
+        ke = __builtin_amdgcn_readfirstlane((slice + 1) * nk / splits);
     }
     constexpr int GM = 4;
     const int group = wg / (GM * tiles_n);
@@ -312,7 +330,7 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
 
     // LOAD(t, kk): the 12 fragments of K-half kk (32 deep) of tile t -> 48 VGPRs
     auto LOAD = [&](int t, int kk, int slot) {
-        const uint16_t* la = smem + (t & 1) * BUF;
+        const uint16_t* la = smem + ((t - kb) & 1) * BUF;
         const uint16_t* lb = la + TM * BK;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -332,15 +350,14 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
             for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<BF16>(bf[slot][j], af[slot][i], acc[i][j]);
     };
 
-    const int nk = K / BK;
     const uint32_t lds0 = lds_addr_of(smem);
     TileLanes<8> ta, tw;
     ta.init(lda, row0, M, wave, lane);
     tw.init(ldw, col0, N, wave, lane);
     const uint16_t* abase = A + (int64_t)row0 * lda;
     const uint16_t* wbase = W + (int64_t)col0 * ldw;
-    stage_tile_dma<8>(ta, abase, lds0, wave);
-    stage_tile_dma<8>(tw, wbase, lds0 + TM * BK * 2, wave);
+    stage_tile_dma<8>(ta, abase + kb * BK, lds0, wave);
+    stage_tile_dma<8>(tw, wbase + kb * BK, lds0 + TM * BK * 2, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -349,9 +366,9 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     // Tile t+1 goes in flight at the start of tile t and must have landed one step before group 0 reads it:
     // group 0 drains its share at the end of its last step of the tile, group 1 (a step late) one step earlier.
     if (grp == 1) __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) {
-            const uint32_t nxt = lds0 + ((t + 1) & 1) * (BUF * 2);
+    for (int t = kb; t < ke; ++t) {
+        if (t + 1 < ke) {
+            const uint32_t nxt = lds0 + ((t + 1 - kb) & 1) * (BUF * 2);
             stage_tile_dma<8>(ta, abase + (t + 1) * BK, nxt, wave);
             stage_tile_dma<8>(tw, wbase + (t + 1) * BK, nxt + TM * BK * 2, wave);
         }
@@ -388,6 +405,95 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
 
+    if constexpr (SPLIT) {
+        if (tail_idx >= 0) {
+            // Partials travel with system-scope stores/loads (sc0 sc1), not agent-scope fences: a fence writes back / invalidates
+            // the XCD's whole L2 under every other workgroup's operand stream.  SGPR base + one VGPR offset per access.
+            constexpr uint32_t ROW = T_THREADS * 16u;                              // one float4 per thread
+            constexpr uint32_t SLOT = 32u * ROW;                                   // 256 KiB of fp32 per (tile, slice)
+            const char* tile_ws = reinterpret_cast<const char*>(ws) + (int64_t)tail_idx * splits * SLOT;
+            {
+                const char* slot = tile_ws + (int64_t)slice * SLOT;
+                uint32_t vo = (uint32_t)tid * 16u;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\tv_add_u32 %0, 0x2000, %0" : "+v"(vo) : "v"(acc[i][j]), "s"(slot) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // arrive, then wait for the other slices of this tile.  All slices of all tail tiles fit one round (tail * splits <=
+            // CUs), so they are resident together and the wait cannot deadlock.
+            if (tid == 0) {
+                __hip_atomic_fetch_add(counters + tail_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                while (__hip_atomic_load(counters + tail_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (uint32_t)splits) __builtin_amdgcn_s_sleep(2);
+            }
+            __syncthreads();
+            // reduce-scatter: the tile's 16 (row group, column pair) units are dealt out to the slices; each slice sums ITS units
+            // over all slices in slice order (deterministic) and runs the fused epilogue on them -- the fix-up is parallel
+            // over the slices instead of one workgroup reading splits x 256 KiB.
+            const int u0 = slice * 16 / splits, u1 = (slice + 1) * 16 / splits;
+            for (int u = u0; u < u1; u += 2) {
+                float4v part[2][8][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int uu = (u + h < u1) ? u + h : u;                    // (odd count: the second half repeats the first, unused)
+                    const char* unit = tile_ws + (uint32_t)(uu * 2) * ROW;      // slot e = i*4 + j with i = uu/2, j = (uu&1)*2 -> e = uu*2
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl) {
+                        part[h][sl][0] = float4v{0.f, 0.f, 0.f, 0.f};
+                        part[h][sl][1] = float4v{0.f, 0.f, 0.f, 0.f};
+                        if (sl < splits) {
+                            const char* src = unit + (int64_t)sl * SLOT;
+                            const uint32_t vo = (uint32_t)tid * 16u;
+                            asm volatile("global_load_dwordx4 %0, %2, %3 sc0 sc1\n\tglobal_load_dwordx4 %1, %2, %4 sc0 sc1"
+                                         : "=&v"(part[h][sl][0]), "=&v"(part[h][sl][1])
+                                         : "v"(vo), "s"(src), "s"(src + ROW)
+                                         : "memory");
+                        }
+                    }
+                }
+                // these loads are invisible to hipcc's waitcnt bookkeeping: tie every result to the wait
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(part[h][0][0]), "+v"(part[h][0][1]), "+v"(part[h][1][0]), "+v"(part[h][1][1]), "+v"(part[h][2][0]), "+v"(part[h][2][1]),
+                                   "+v"(part[h][3][0]), "+v"(part[h][3][1]), "+v"(part[h][4][0]), "+v"(part[h][4][1]), "+v"(part[h][5][0]), "+v"(part[h][5][1]),
+                                   "+v"(part[h][6][0]), "+v"(part[h][6][1]), "+v"(part[h][7][0]), "+v"(part[h][7][1])
+                                 :
+                                 : "memory");
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (u + h >= u1) break;
+                    float4v s0 = part[h][0][0], s1 = part[h][0][1];
+#pragma unroll
+                    for (int sl = 1; sl < 8; ++sl) {                            // (slices >= splits hold zeros)
+                        s0 += part[h][sl][0];
+                        s1 += part[h][sl][1];
+                    }
+                    const int uu = u + h;
+                    const int m = row0 + grp * 128 + (uu >> 1) * 16 + fi;
+                    const int n16 = col0 + wn * 64 + (uu & 1) * 32;
+                    if (m < M) {
+                        if constexpr (EPI == EPI_SWIGLU) {
+                            store4<BF16, EPI>(s0, s1, C, bias, residual, m, n16, fg, ldc);
+                        } else {
+                            store4<BF16, EPI>(s0, s0, C, bias, residual, m, n16, fg, ldc);
+                            store4<BF16, EPI>(s1, s1, C, bias, residual, m, n16 + 16, fg, ldc);
+                        }
+                    }
+                }
+            }
+            // leave; the last slice to leave re-arms the counter for the next launch on this stream
+            if (tid == 0) {
+                if (__hip_atomic_fetch_add(counters + tail_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == (uint32_t)(2 * splits - 1))
+                    __hip_atomic_store(counters + tail_idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+    }
+
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = row0 + grp * 128 + i * 16 + fi;
@@ -409,11 +515,82 @@ int32_t launch256(const void* A, const void* W, void* C, const void* bias, const
     const size_t sh = 2 * 2 * TM * BK * sizeof(uint16_t);   // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, KFULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, KFULL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
-                       (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn);
+    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL, false>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W,
+                       (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, 1, (float*)nullptr, (uint32_t*)nullptr);
+    D3D_LAUNCH_CHECK();
+}
+
+// Per-stream workspace of the split-K tail: 256 KiB of fp32 per (tail tile, slice) -- at most one round of them -- and one
+// arrival counter per tail tile (the last slice to arrive resets it).  Streams never share a workspace.
+struct SplitWorkspace {
+    float* ws = nullptr;
+    uint32_t* counters = nullptr;
+    int slots = 0;
+};
+
+int32_t split_workspace(hipStream_t s, int slots, SplitWorkspace** out) {
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, SplitWorkspace> table;
+    std::lock_guard<std::mutex> lock(mu);
+    SplitWorkspace& w = table[s];
+    if (w.slots < slots) {
+        if (w.ws) (void)hipFree(w.ws);
+        if (w.counters) (void)hipFree(w.counters);
+        w.ws = nullptr;
+        w.counters = nullptr;
+        w.slots = 0;
+        D3D_HIP(hipMalloc(&w.ws, (size_t)slots * 32 * T_THREADS * sizeof(float4v)));
+        D3D_HIP(hipMalloc(&w.counters, (size_t)slots * sizeof(uint32_t)));
+        D3D_HIP(hipMemset(w.counters, 0, (size_t)slots * sizeof(uint32_t)));
+        w.slots = slots;
+    }
+    *out = &w;
+    return D3D_OK;
+}
+
+int cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus;
+}
+
+// Split plan for M x N output tiles of 256 x 256: full rounds stay whole; the remainder is cut `splits` ways if that fits one round.
+inline void split_plan(int tiles, int nk, int* dp_tiles, int* splits) {
+    const int P = cu_count();
+    const int tail = tiles % P;
+    int sp = tail ? P / tail : 1;
+    if (sp > 8) sp = 8;
+    if (sp > nk) sp = nk;
+    *dp_tiles = tiles - tail;
+    *splits = sp < 1 ? 1 : sp;
+}
+
+template <bool BF16, int EPI>
+int32_t launch256_split(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
+                        int64_t ldw, int64_t ldc, hipStream_t s) {
+    const int tm = (M + TM - 1) / TM, tn = N / TN, tiles = tm * tn;
+    int dp_tiles, splits;
+    split_plan(tiles, K / BK, &dp_tiles, &splits);
+    if (splits < 2) return launch256<BF16, EPI, true>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s);
+    const int tail = tiles - dp_tiles;
+    SplitWorkspace* w = nullptr;
+    int32_t rc = split_workspace(s, cu_count(), &w);
+    if (rc != D3D_OK) return rc;
+    const size_t sh = 2 * 2 * TM * BK * sizeof(uint16_t);   // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, true, true>), dim3(dp_tiles + tail * splits), dim3(T_THREADS), sh, s, (const uint16_t*)A,
+                       (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, dp_tiles,
+                       splits, w->ws, w->counters);
     D3D_LAUNCH_CHECK();
 }
 
@@ -443,13 +620,24 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
 
 int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
                     int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, void* stream) {
-    // Tile choice.  The 256x256 staggered kernel runs one workgroup per CU, so it pays when its grid covers the 256 CUs
-    // for several rounds; its M remainder (M % 256 rows) goes to the 128x128 kernel instead of a mostly-empty row of
-    // 256-tiles (at M = 7200 that turns 29 x N/256 workgroups = 7.25 rounds into 28 x N/256 = exactly 7 for N = 16384).
+    // Tile choice.  The 256x256 staggered kernel runs one workgroup per CU, so it pays when its grid covers the CUs for
+    // several rounds; its M remainder (M % 256 rows) goes to the 128x128 kernel instead of a mostly-empty row of 256-tiles
+    // (at M = 7200 that turns 29 x N/256 workgroups = 7.25 rounds into 28 x N/256 = exactly 7 for N = 16384).
+    // Between one and three rounds the partial last round decides: it is K-split when it can be cut at least four ways
+    // (o_proj / down_proj at M = 6400: 300 tiles = one round + 44 tiles x 5 slices; measured 0.120 / 0.277 ms against
+    // 0.132 / 0.306 ms for the 128x128 kernel and 0.148 / 0.330 ms unsplit); otherwise the finer 128x128 grid wins.
     const int64_t rows256 = (int64_t)(M / TM) * TM;
     const int64_t blocks256 = (rows256 / TM) * (N / TN);
+    int tile = 128;
     if (N % TN == 0 && blocks256 >= 768) {
-        int32_t rc = d3d_gemm_nt_tile(A, W, C, bias, residual, (int32_t)rows256, N, K, lda, ldw, ldc, dtype, epilogue, 257, stream);
+        tile = 257;
+    } else if (N % TN == 0 && blocks256 >= 256) {
+        int dp_tiles, splits;
+        split_plan((int)blocks256, K / BK, &dp_tiles, &splits);
+        if (splits >= 4 && (K / BK) / splits >= 8) tile = 258;
+    }
+    if (tile != 128) {
+        int32_t rc = d3d_gemm_nt_tile(A, W, C, bias, residual, (int32_t)rows256, N, K, lda, ldw, ldc, dtype, epilogue, tile, stream);
         if (rc != D3D_OK || rows256 == M) return rc;
         const char* a8 = (const char*)A + rows256 * lda * 2;
         char* c8 = (char*)C + rows256 * ldc * 2;
@@ -462,8 +650,8 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
 int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream) {
     if (M <= 0) return D3D_OK;
-    if (tile != 128 && tile != 256 && tile != 257) {
-        d3d_set_error_("d3d_gemm_nt_tile: tile must be 128, 256 (K-half steps) or 257 (whole-K-tile steps)");
+    if (tile != 128 && tile != 256 && tile != 257 && tile != 258) {
+        d3d_set_error_("d3d_gemm_nt_tile: tile must be 128, 256 (K-half steps), 257 (whole-K-tile steps) or 258 (257 + split-K tail)");
         return D3D_EINVAL;
     }
     if (tile >= 256 && N % TN != 0) {
@@ -480,6 +668,9 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
         if (tile == 256)                                                                                              \
             return dtype == 0 ? launch256<true, E, false>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)          \
                               : launch256<false, E, false>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);        \
+        if (tile == 258)                                                                                              \
+            return dtype == 0 ? launch256_split<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)           \
+                              : launch256_split<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);         \
         if (tile == 257)                                                                                              \
             return dtype == 0 ? launch256<true, E, true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)           \
                               : launch256<false, E, true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);         \

@@ -52,7 +52,7 @@ class HipDense:
         return (w.shape[0] % 128 == 0 and K % 64 == 0 and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16)
                 and x.stride(-1) == 1 and w.is_contiguous())
 
-    TILE = 0   # 0 = library heuristic, 128 / 256 / 257 = force a tile (benchmarking, tests)
+    TILE = 0   # 0 = library heuristic, 128 / 256 / 257 / 258 = force a tile (benchmarking, tests)
 
     def gemm(self, x, w, bias, residual, epi: str):
         M, K = x.shape
@@ -64,10 +64,6 @@ class HipDense:
         dt = 0 if x.dtype == torch.bfloat16 else 1
         if self.TILE:
             tile = self.TILE if (self.TILE < 256 or N % 256 == 0) else 128
-            if tile == 257 and epi not in ('none', 'swiglu'):
-                tile = 256
-            if tile in (258, 259) and epi != 'none':
-                tile = 256
             _lib.check(self.lib.d3d_gemm_nt_tile(_p(x), _p(w), _p(out), _p(bias), _p(residual), M, N, K, x.stride(0), w.stride(0), n_out,
                                                  dt, EPI[epi], tile, self._stream()))
         else:

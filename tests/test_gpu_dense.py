@@ -74,6 +74,32 @@ def test_gemm_256_tile_kernels(hd, dt, tol, tile):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
+def test_gemm_split_k_tail(hd, dt, tol):
+    """Tile code 258: whole rounds of 256x256 tiles data-parallel + the remainder tiles cut into K-slices whose last arriver
+    reduces them in slice order.  Shapes: tail only (4, 44, 100 tiles -> 8, 5, 2 slices), rounds + tail, slices > K tiles,
+    no tail at all; repeated launches reuse the counters; results are bit-identical from launch to launch."""
+    from dynam3d_amd.hip_dense import HipDense, interleave_gate_up
+    torch.manual_seed(3)
+    try:
+        HipDense.TILE = 258
+        for M, N, K in ((512, 512, 1024), (2816, 1024, 2048), (6400, 1024, 512), (6400, 3072, 3072), (512, 512, 128), (4096, 4096, 256)):
+            x = (torch.randn(M, K, device="cuda") * 0.7).to(dt)
+            w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
+            w[3] *= 4.0
+            x[:, 5] += 1.0
+            b = (torch.randn(N, device="cuda") * 0.3).to(dt)
+            r = torch.randn(M, N, device="cuda").to(dt)
+            y32 = x.float() @ w.float().t()
+            for rep in range(2):
+                assert rel(hd.linear(x, w, None, None).float(), y32) < tol, (M, N, K, "none")
+                assert rel(hd.linear(x, w, b, None, r).float(), y32 + b.float() + r.float()) < tol, (M, N, K, "bias_res")
+                assert rel(hd.linear_swiglu(x, interleave_gate_up(w)).float(), y32[:, N // 2:] * F.silu(y32[:, :N // 2])) < tol, (M, N, K, "swiglu")
+            assert torch.equal(hd.linear(x, w, None, None, r), hd.linear(x, w, None, None, r))
+    finally:
+        HipDense.TILE = 0
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
 def test_norms_rope_swiglu(hd, dt, tol):
     torch.manual_seed(2)
     for D in (768, 1024, 3072, 4096, 128):

@@ -50,7 +50,7 @@ for dt in (torch.bfloat16, torch.float16):
             own = lambda: hd.linear(x, w, b, "quick_gelu")
         yr = ref().float()
         res = {}
-        for tile in (128, 256, 257, 0):
+        for tile in (128, 257, 258, 0):
             if tile >= 256 and n % 256:
                 continue
             HipDense.TILE = tile
