@@ -248,7 +248,27 @@ k_set_attention(const float* __restrict__ qkv, const int32_t* __restrict__ off, 
         }
         __syncthreads();
         if (active) {
-            for (int r = 0; r < cnt; ++r) {
+            // four keys per step: four independent 64-deep dot-product chains (the single chain was latency bound), one
+            // rescale of the accumulator per step instead of per key
+            int r = 0;
+            for (; r + 4 <= cnt; r += 4) {
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) {
+                    s0 += q[d] * ks[r][d];
+                    s1 += q[d] * ks[r + 1][d];
+                    s2 += q[d] * ks[r + 2][d];
+                    s3 += q[d] * ks[r + 3][d];
+                }
+                const float mn = fmaxf(fmaxf(m, fmaxf(s0, s1)), fmaxf(s2, s3));
+                const float a = __expf(m - mn);
+                const float p0 = __expf(s0 - mn), p1 = __expf(s1 - mn), p2 = __expf(s2 - mn), p3 = __expf(s3 - mn);
+                l = l * a + ((p0 + p1) + (p2 + p3));
+#pragma unroll
+                for (int d = 0; d < HD; ++d) o[d] = o[d] * a + ((p0 * vs[r][d] + p1 * vs[r + 1][d]) + (p2 * vs[r + 2][d] + p3 * vs[r + 3][d]));
+                m = mn;
+            }
+            for (; r < cnt; ++r) {
                 float sdot = 0.f;
 #pragma unroll
                 for (int d = 0; d < HD; ++d) sdot += q[d] * ks[r][d];
@@ -267,6 +287,65 @@ k_set_attention(const float* __restrict__ qkv, const int32_t* __restrict__ off, 
 #pragma unroll
         for (int d = 0; d < HD; ++d) op[d] = o[d] * inv;
     }
+}
+
+// CLS-only variant (q_rows == 1: the last encoder layer, whose other rows are never read).  One wave per (set, head): the
+// keys are dealt out to the 64 lanes (lane j scores keys j, j+64, ...), softmax statistics are wave reductions, and lane d
+// sums column d of the probability-weighted values -- instead of one active thread walking all L keys.
+__global__ void __launch_bounds__(64)
+k_set_attention_cls(const float* __restrict__ qkv, const int32_t* __restrict__ off, int H, float* __restrict__ out) {
+    constexpr int HD = 64;
+    __shared__ float qs[HD];
+    __shared__ float ps[64];
+    const int g = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int t0 = off[g], L = off[g + 1] - t0;
+    if (L <= 0) return;
+    const int64_t ld = (int64_t)3 * H * HD;
+    qs[lane] = qkv[(int64_t)t0 * ld + h * HD + lane] * 0.125f;
+    __syncthreads();
+    float m = -INFINITY, l = 0.f, o = 0.f;                  // lane d accumulates output column d
+    for (int k0 = 0; k0 < L; k0 += 64) {
+        const int r = k0 + lane;
+        float sdot = -INFINITY;
+        if (r < L) {
+            const float* kp = qkv + (int64_t)(t0 + r) * ld + H * HD + h * HD;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const float4 kv = *reinterpret_cast<const float4*>(kp + d);
+                s0 += qs[d] * kv.x;
+                s1 += qs[d + 1] * kv.y;
+                s2 += qs[d + 2] * kv.z;
+                s3 += qs[d + 3] * kv.w;
+            }
+            sdot = (s0 + s1) + (s2 + s3);
+        }
+        float tmax = sdot;
+#pragma unroll
+        for (int w = 32; w >= 1; w >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, w, 64));
+        const float mn = fmaxf(m, tmax);
+        const float a = __expf(m - mn);
+        const float p = r < L ? __expf(sdot - mn) : 0.f;
+        float psum = p;
+#pragma unroll
+        for (int w = 32; w >= 1; w >>= 1) psum += __shfl_xor(psum, w, 64);
+        l = l * a + psum;
+        __syncthreads();
+        ps[lane] = p;
+        __syncthreads();
+        const int cnt = min(64, L - k0);
+        const float* vp = qkv + (int64_t)(t0 + k0) * ld + 2 * H * HD + h * HD + lane;
+        float acc0 = 0.f, acc1 = 0.f;
+        int j = 0;
+        for (; j + 2 <= cnt; j += 2) {
+            acc0 += ps[j] * vp[(int64_t)j * ld];
+            acc1 += ps[j + 1] * vp[(int64_t)(j + 1) * ld];
+        }
+        if (j < cnt) acc0 += ps[j] * vp[(int64_t)j * ld];
+        o = o * a + (acc0 + acc1);
+        m = mn;
+    }
+    out[(int64_t)t0 * (H * HD) + h * HD + lane] = o / l;
 }
 
 template <bool BF16, bool RMS>
@@ -345,8 +424,12 @@ int32_t d3d_set_attention(const float* qkv, const int32_t* set_off, int32_t n_se
                           float* out, void* stream) {
     if (n_sets <= 0 || max_len <= 0) return D3D_OK;
     const int nq = q_rows > 0 ? (q_rows < max_len ? q_rows : max_len) : max_len;
-    dim3 grid(n_sets, n_heads, (nq + 63) / 64);
-    hipLaunchKernelGGL(k_set_attention, grid, dim3(64), 0, (hipStream_t)stream, qkv, set_off, n_heads, q_rows, out);
+    if (q_rows == 1) {
+        hipLaunchKernelGGL(k_set_attention_cls, dim3(n_sets, n_heads), dim3(64), 0, (hipStream_t)stream, qkv, set_off, n_heads, out);
+    } else {
+        dim3 grid(n_sets, n_heads, (nq + 63) / 64);
+        hipLaunchKernelGGL(k_set_attention, grid, dim3(64), 0, (hipStream_t)stream, qkv, set_off, n_heads, q_rows, out);
+    }
     D3D_LAUNCH_CHECK();
 }
 
