@@ -176,7 +176,10 @@ __device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint1
     }
 }
 
-template <bool BF16, int EPI>
+// NSTAGE = LDS K-tile ring depth.  2 (64 KiB, two workgroups per CU) is the throughput configuration; 4 (128 KiB, one
+// workgroup per CU) keeps three K tiles in flight for grids that cannot give every CU two workgroups anyway (the ViT
+// projections at M = 2056: 136 tiles) -- there a K step is bounded by the LDS-DMA latency, not by its 32 MFMAs.
+template <bool BF16, int EPI, int NSTAGE>
 __global__ void __launch_bounds__(NTHREADS, 2)
 k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* __restrict__ C,
           const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, int M, int N, int K, int64_t lda,
@@ -214,20 +217,30 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
     tw.init(ldw, col0, N, wave, lane);
     const uint16_t* abase = A + (int64_t)row0 * lda;
     const uint16_t* wbase = W + (int64_t)col0 * ldw;
-    stage_tile_dma<4>(ta, abase, lds0, wave);
-    stage_tile_dma<4>(tw, wbase, lds0 + BM * BK * 2, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    constexpr uint32_t STAGE_BYTES = 2 * BM * BK * 2;                  // A tile + B tile
+    auto STAGE = [&](int t) {
+        const uint32_t d = lds0 + (uint32_t)(t % NSTAGE) * STAGE_BYTES;
+        stage_tile_dma<4>(ta, abase + t * BK, d, wave);
+        stage_tile_dma<4>(tw, wbase + t * BK, d + BM * BK * 2, wave);
+    };
+#pragma unroll
+    for (int t = 0; t < NSTAGE - 1; ++t)
+        if (t < nk) STAGE(t);
 
     const int fi = lane & 15, fg = lane >> 4;               // fragment row, k-group
     for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) {
-            const uint32_t nxt = lds0 + (cur ^ 1) * (2 * BM * BK * 2);
-            stage_tile_dma<4>(ta, abase + (t + 1) * BK, nxt, wave);
-            stage_tile_dma<4>(tw, wbase + (t + 1) * BK, nxt + BM * BK * 2, wave);
+        // tile t has landed when at most the (up to NSTAGE-2) younger tiles are still in flight: 8 LDS-DMA per wave and tile
+        const int younger = min(t + NSTAGE - 2, nk - 1) - t;
+        if (NSTAGE > 3 && younger >= 2) {
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else if (NSTAGE > 2 && younger == 1) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        const uint16_t* la = smem + cur * (2 * BM * BK);
+        __builtin_amdgcn_s_barrier();                          // tile t visible to all; everyone is done reading tile t-1
+        if (t + NSTAGE - 1 < nk) STAGE(t + NSTAGE - 1);         // ... whose buffer the new tile takes
+        const uint16_t* la = smem + (t % NSTAGE) * (2 * BM * BK);
         const uint16_t* lb = la + BM * BK;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -244,8 +257,7 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<BF16>(bf[j], af[i], acc[i][j]);   // D = C^T tile: rows n, cols m
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 
     // ---- epilogue: lane holds, for tile (i,j): row m = row0+wr*64+i*16+fi, cols n = col0+wc*64+j*16+fg*4 .. +3
@@ -594,19 +606,29 @@ int32_t launch256_split(const void* A, const void* W, void* C, const void* bias,
     D3D_LAUNCH_CHECK();
 }
 
-template <bool BF16, int EPI>
-int32_t launch(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
-               int64_t ldw, int64_t ldc, hipStream_t s) {
+template <bool BF16, int EPI, int NSTAGE>
+int32_t launch_stages(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
+                      int64_t ldw, int64_t ldc, hipStream_t s) {
     const int tm = (M + BM - 1) / BM, tn = N / BN;
-    const size_t sh = 4 * BM * BK * sizeof(uint16_t);
+    const size_t sh = (size_t)NSTAGE * 2 * BM * BK * sizeof(uint16_t);
     static bool attr_set = false;
     if (!attr_set) {
-        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<BF16, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<BF16, EPI, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_nt<BF16, EPI>), dim3(tm * tn), dim3(NTHREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
+    hipLaunchKernelGGL((k_gemm_nt<BF16, EPI, NSTAGE>), dim3(tm * tn), dim3(NTHREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
                        (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn);
     D3D_LAUNCH_CHECK();
+}
+
+// 128 x 128 tile: ring depth by grid size (see k_gemm_nt)
+template <bool BF16, int EPI>
+int32_t launch(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
+               int64_t ldw, int64_t ldc, hipStream_t s, int stages = 0) {
+    const int tiles = ((M + BM - 1) / BM) * (N / BN);
+    if (stages == 0) stages = (tiles <= cu_count() && K / BK >= 4) ? 4 : 2;
+    return stages == 4 ? launch_stages<BF16, EPI, 4>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s)
+                       : launch_stages<BF16, EPI, 2>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s);
 }
 
 }  // namespace
@@ -629,8 +651,8 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
     const int64_t rows256 = (int64_t)(M / TM) * TM;
     const int64_t blocks256 = (rows256 / TM) * (N / TN);
     int tile = 128;
-    if (N % TN == 0 && blocks256 >= 768) {
-        tile = 257;
+    if (N % TN == 0 && (blocks256 >= 768 || (blocks256 <= cu_count() && blocks256 * 4 >= cu_count() * 3))) {
+        tile = 257;               // several rounds, or one nearly full round (ViT qkv at M = 4616: 216 tiles, 41.6 us against 46.3 us)
     } else if (N % TN == 0 && blocks256 >= 256) {
         int dp_tiles, splits;
         split_plan((int)blocks256, K / BK, &dp_tiles, &splits);
@@ -650,8 +672,8 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
 int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream) {
     if (M <= 0) return D3D_OK;
-    if (tile != 128 && tile != 256 && tile != 257 && tile != 258) {
-        d3d_set_error_("d3d_gemm_nt_tile: tile must be 128, 256 (K-half steps), 257 (whole-K-tile steps) or 258 (257 + split-K tail)");
+    if (tile != 128 && tile != 130 && tile != 132 && tile != 256 && tile != 257 && tile != 258) {
+        d3d_set_error_("d3d_gemm_nt_tile: tile must be 128 (130 / 132: 2 / 4 LDS stages forced), 256 (K-half steps), 257 (whole-K-tile steps) or 258 (257 + split-K tail)");
         return D3D_EINVAL;
     }
     if (tile >= 256 && N % TN != 0) {
@@ -674,8 +696,8 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
         if (tile == 257)                                                                                              \
             return dtype == 0 ? launch256<true, E, true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)           \
                               : launch256<false, E, true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);         \
-        return dtype == 0 ? launch<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)                        \
-                          : launch<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);
+        return dtype == 0 ? launch<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s, tile == 128 ? 0 : tile - 128)  \
+                          : launch<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s, tile == 128 ? 0 : tile - 128);
     switch (epilogue) {
         D3D_GEMM_CASE(EPI_NONE)
         D3D_GEMM_CASE(EPI_BIAS)

@@ -52,7 +52,7 @@ class HipDense:
         return (w.shape[0] % 128 == 0 and K % 64 == 0 and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16)
                 and x.stride(-1) == 1 and w.is_contiguous())
 
-    TILE = 0   # 0 = library heuristic, 128 / 256 / 257 / 258 = force a tile (benchmarking, tests)
+    TILE = 0   # 0 = library heuristic, 128 / 130 / 132 / 256 / 257 / 258 = force a kernel variant (benchmarking, tests)
 
     def gemm(self, x, w, bias, residual, epi: str):
         M, K = x.shape

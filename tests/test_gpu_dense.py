@@ -48,11 +48,12 @@ def test_gemm_epilogues_asymmetric(hd, dt, tol):
         assert rel(hd.linear(big[:, :K], w, None, None).float(), big[:, :K].float() @ w.float().t()) < tol
 
 
-@pytest.mark.parametrize("tile", [256, 257])
+@pytest.mark.parametrize("tile", [130, 132, 256, 257])
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
-def test_gemm_256_tile_kernels(hd, dt, tol, tile):
-    """The 256x256x64 staggered kernel forced explicitly in both step sizes (256 = K-half steps, 257 = whole-K-tile steps):
-    ragged M, one and many K tiles, every fused epilogue."""
+def test_gemm_forced_tile_kernels(hd, dt, tol, tile):
+    """Every kernel variant forced explicitly -- 128x128 with a 2- / 4-deep LDS ring (130 / 132), 256x256x64 staggered in
+    both step sizes (256 = K-half steps, 257 = whole-K-tile steps): ragged M, fewer K tiles than ring slots, many K tiles,
+    every fused epilogue."""
     from dynam3d_amd.hip_dense import HipDense, interleave_gate_up
     torch.manual_seed(2)
     try:
