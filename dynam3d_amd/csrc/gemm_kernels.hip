@@ -578,7 +578,7 @@ inline void split_plan(int tiles, int nk, int* dp_tiles, int* splits) {
     const int tail = tiles % P;
     int sp = tail ? P / tail : 1;
     if (sp > 8) sp = 8;
-    if (sp > nk) sp = nk;
+    if (sp > nk / 8) sp = nk / 8;          // a slice keeps at least 8 K steps: shorter ones are all pipeline fill and fix-up
     *dp_tiles = tiles - tail;
     *splits = sp < 1 ? 1 : sp;
 }
@@ -645,7 +645,7 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
     // Tile choice.  The 256x256 staggered kernel runs one workgroup per CU, so it pays when its grid covers the CUs for
     // several rounds; its M remainder (M % 256 rows) goes to the 128x128 kernel instead of a mostly-empty row of 256-tiles
     // (at M = 7200 that turns 29 x N/256 workgroups = 7.25 rounds into 28 x N/256 = exactly 7 for N = 16384).
-    // Between one and three rounds the partial last round decides: it is K-split when it can be cut at least four ways
+    // Between one and three rounds the partial last round decides: it is K-split when it can be cut at least three ways
     // (o_proj / down_proj at M = 6400: 300 tiles = one round + 44 tiles x 5 slices; measured 0.120 / 0.277 ms against
     // 0.132 / 0.306 ms for the 128x128 kernel and 0.148 / 0.330 ms unsplit); otherwise the finer 128x128 grid wins.
     const int64_t rows256 = (int64_t)(M / TM) * TM;
@@ -656,7 +656,7 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
     } else if (N % TN == 0 && blocks256 >= 256) {
         int dp_tiles, splits;
         split_plan((int)blocks256, K / BK, &dp_tiles, &splits);
-        if (splits >= 4 && (K / BK) / splits >= 8) tile = 258;
+        if (splits >= 3) tile = 258;
     }
     if (tile != 128) {
         int32_t rc = d3d_gemm_nt_tile(A, W, C, bias, residual, (int32_t)rows256, N, K, lda, ldw, ldc, dtype, epilogue, tile, stream);
