@@ -28,6 +28,7 @@ import torch
 
 from . import dense_ops as D
 from .feature_fields import Feature_Fields
+from .profiling import TIMER
 from .towers import (ClipVisionTower, LlavaVisionTower, Phi3Config, Phi3Decoder, VitConfig, clip_param_spec,
                      llava_vision_param_spec, phi3_param_spec, preprocess_rgb)
 from .weights import ff_param_spec, synth_state_dict
@@ -187,21 +188,64 @@ class Dynam3D_VLN:
             ff.delete_old_features_from_camera_frustum(dfull, agent_positions, agent_heading_angles, num_of_views=V)
         ff.update_feature_fields(depth24, grid.view(B, V, ff.P, -1), rgb, agent_positions, agent_heading_angles, num_of_views=V,
                                  patch_segm=patch_segm)
-        env = ff.get_environment_features(agent_positions, agent_heading_angles)
-        rel_x, rel_y, rel_z, direction, scale = ff.get_patch_3d_info(depth24.reshape(B * V, -1))
-        info = torch.cat([rel_x, rel_y, rel_z, torch.sin(direction), torch.cos(direction), scale], dim=-1)   # VLN-POL:432
-        patch_pos = self._mlp(info, "patch_position_embedding", lowp=True)                    # (B*V,576,3072)
-        ni = [int(t.shape[0]) for t in env["batch_instance_fts"]]
-        nz = [int(t.shape[0]) for t in env["batch_zone_fts"]]
-        ifts, irel = torch.cat(env["batch_instance_fts"]), torch.cat(env["batch_instance_relative_position"])
-        zfts, zrel = torch.cat(env["batch_zone_fts"]), torch.cat(env["batch_zone_relative_position"])
-        inst_tok = self._mlp(torch.cat([ifts, self._mlp(irel, "instance_position_embedding")], -1), "instance_projector")   # VLN-POL:434
-        zone_tok = self._mlp(torch.cat([zfts, self._mlp(zrel, "zone_position_embedding")], -1), "zone_projector")           # VLN-POL:435
+        with TIMER.range("prefix.query"):
+            env = ff.get_environment_features(agent_positions, agent_heading_angles)
+        with TIMER.range("prefix.mlps"):
+            rel_x, rel_y, rel_z, direction, scale = ff.get_patch_3d_info(depth24.reshape(B * V, -1))
+            info = torch.cat([rel_x, rel_y, rel_z, torch.sin(direction), torch.cos(direction), scale], dim=-1)   # VLN-POL:432
+            patch_pos = self._mlp(info, "patch_position_embedding", lowp=True)                    # (B*V,576,3072)
+            ni = [int(t.shape[0]) for t in env["batch_instance_fts"]]
+            nz = [int(t.shape[0]) for t in env["batch_zone_fts"]]
+            ifts, irel = torch.cat(env["batch_instance_fts"]), torch.cat(env["batch_instance_relative_position"])
+            zfts, zrel = torch.cat(env["batch_zone_fts"]), torch.cat(env["batch_zone_relative_position"])
+            inst_tok = self._mlp(torch.cat([ifts, self._mlp(irel, "instance_position_embedding")], -1), "instance_projector")   # VLN-POL:434
+            zone_tok = self._mlp(torch.cat([zfts, self._mlp(zrel, "zone_position_embedding")], -1), "zone_projector")           # VLN-POL:435
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             patch_feat.record_stream(torch.cuda.current_stream())
         else:
             patch_feat = self.llava_vision.forward(pixels)
+        with TIMER.range("prefix.rows"):
+            if return_rows == "packed":
+                return self._assemble_packed(patch_feat, patch_pos, inst_tok, zone_tok, ni, nz, instructions, B, V)
+            return self._assemble_rows(patch_feat, patch_pos, inst_tok, zone_tok, ni, nz, instructions, B, V, return_rows)
+
+    def _prompt_text(self, b, instructions):
+        return ("\nInstruction:\n" + instructions[b] + "\nHistory actions:\n" + "".join(self.feature_fields.history_actions[b])
+                + "<|end|>\n<|assistant|>\nNext action:\n")
+
+    def _assemble_packed(self, patch_feat, patch_pos, inst_tok, zone_tok, ni, nz, instructions, B, V):
+        """Same rows as `_assemble_rows`, written once, in the LM's dtype, back to back (no per-environment tensors, no
+        padding): one id upload + one embedding gather for all prompts, one add for all patch tokens, one row gather into
+        the packed buffer.  Returns (x (Tp, hidden) with Tp = sum(lengths) rounded up to 256 rows, lengths)."""
+        ff, tok, dt = self.feature_fields, self.tokenizer, self.cfg.llava_dtype
+        P = V * ff.P
+        head_ids = tok.encode("<|user|>", bos=True)
+        text_ids = [tok.encode(self._prompt_text(b, instructions)) for b in range(B)]
+        ids = torch.tensor(head_ids + [i for t in text_ids for i in t], device=self.device)
+        emb = self.llm.embed_tokens(ids).to(dt)                                                # rows [0, E)
+        patch_tok = (patch_feat.reshape(B * P, -1).float() + patch_pos.reshape(B * P, -1).float()).to(dt)   # VLN-POL:448-453
+        src = torch.cat([emb, patch_tok, inst_tok.to(dt), zone_tok.to(dt)], 0)
+        E, nh = emb.shape[0], len(head_ids)
+        o_patch, o_inst, o_zone = E, E + B * P, E + B * P + int(sum(ni))
+        idx, lengths = [], []
+        t_off, i_off, z_off = nh, 0, 0
+        for b in range(B):                                                                     # VLN-POL:456 row order
+            n_t = len(text_ids[b])
+            idx.append(np.concatenate([np.arange(nh), o_patch + b * P + np.arange(P), o_inst + i_off + np.arange(ni[b]),
+                                       o_zone + z_off + np.arange(nz[b]), t_off + np.arange(n_t)]))
+            lengths.append(nh + P + ni[b] + nz[b] + n_t)
+            t_off, i_off, z_off = t_off + n_t, i_off + ni[b], z_off + nz[b]
+        T = int(sum(lengths))
+        Tp = (T + 255) // 256 * 256
+        x = torch.zeros((Tp, src.shape[1]), dtype=dt, device=self.device)
+        torch.index_select(src, 0, torch.from_numpy(np.concatenate(idx)).to(self.device), out=x[:T])
+        self.last_lengths = lengths
+        self.last_counts = dict(Ni=ni, Nz=nz)
+        return x, lengths
+
+    def _assemble_rows(self, patch_feat, patch_pos, inst_tok, zone_tok, ni, nz, instructions, B, V, return_rows):
+        ff = self.feature_fields
         patch_tok = patch_feat.float() + patch_pos                                             # VLN-POL:448-453
         patch_tok = patch_tok.view(B, V * ff.P, -1)
         # prompt (VLN-POL:436): ids 0..1 are kept in front of the visual prefix, the text follows it
@@ -211,9 +255,7 @@ class Dynam3D_VLN:
         rows, lengths = [], []
         io, zo = np.concatenate([[0], np.cumsum(ni)]), np.concatenate([[0], np.cumsum(nz)])
         for b in range(B):
-            text = ("\nInstruction:\n" + instructions[b] + "\nHistory actions:\n" + "".join(ff.history_actions[b])
-                    + "<|end|>\n<|assistant|>\nNext action:\n")
-            te = self.llm.embed_tokens(torch.tensor(tok.encode(text), device=self.device)).float()
+            te = self.llm.embed_tokens(torch.tensor(tok.encode(self._prompt_text(b, instructions)), device=self.device)).float()
             row = torch.cat([head_e, patch_tok[b], inst_tok[io[b]:io[b + 1]], zone_tok[zo[b]:zo[b + 1]], te], 0)   # VLN-POL:456
             rows.append(row)
             lengths.append(row.shape[0])
@@ -230,6 +272,10 @@ class Dynam3D_VLN:
     @torch.no_grad()
     def forward_logits(self, observations, instructions, agent_positions, agent_heading_angles, depth_scale=(0.0, 10.0),
                        gt_text=None, delete_old_features=True, num_of_views=1, is_train=False, patch_segm=None) -> torch.Tensor:
+        if self.llm.packed_ok():
+            x, lengths = self.build_inputs(observations, instructions, agent_positions, agent_heading_angles, depth_scale,
+                                           delete_old_features, num_of_views, patch_segm, return_rows="packed")
+            return self.llm.prefill_logits_packed(x, lengths)
         rows, _ = self.build_inputs(observations, instructions, agent_positions, agent_heading_angles, depth_scale,
                                     delete_old_features, num_of_views, patch_segm, return_rows=True)
         return self.llm.prefill_logits_rows(rows)

@@ -255,6 +255,10 @@ class Phi3Decoder:
         return self._rope_cache[S]
 
     @torch.no_grad()
+    def packed_ok(self) -> bool:
+        c = self.cfg
+        return bool(D.packed_ok(self.dtype, c.head_dim) and c.kv_heads == c.heads and self.device.type == "cuda")
+
     def prefill_logits_rows(self, rows) -> torch.Tensor:
         """rows: list of B tensors (S_b, hidden) -- the per-environment prompts.  With the HIP backend the batch is PACKED
         (no padding: sum(S_b) tokens, rounded up to a multiple of 256 rows so every GEMM is whole 256-row tiles) and
@@ -262,7 +266,7 @@ class Phi3Decoder:
         c = self.cfg
         lens = [int(r.shape[0]) for r in rows]
         B = len(rows)
-        if not (D.packed_ok(self.dtype, c.head_dim) and c.kv_heads == c.heads and rows[0].is_cuda):
+        if not (self.packed_ok() and rows[0].is_cuda):
             S = max(lens)
             emb = torch.zeros((B, S, c.hidden), dtype=self.dtype, device=self.device)
             for b, r in enumerate(rows):
@@ -270,8 +274,17 @@ class Phi3Decoder:
             return self.prefill_logits(emb, torch.tensor(lens, device=self.device))
         T = sum(lens)
         Tp = (T + 255) // 256 * 256
-        x = torch.zeros((Tp, c.hidden), dtype=self.dtype, device=self.device)
-        torch.cat([r.to(self.dtype) for r in rows], 0, out=x[:T])
+        with TIMER.range("prefill.pack"):
+            x = torch.zeros((Tp, c.hidden), dtype=self.dtype, device=self.device)
+            torch.cat([r.to(self.dtype) for r in rows], 0, out=x[:T])
+        return self.prefill_logits_packed(x, lens)
+
+    @torch.no_grad()
+    def prefill_logits_packed(self, x: torch.Tensor, lens) -> torch.Tensor:
+        """x (Tp, hidden) in the LM's dtype: the B prompts back to back (lens[b] rows each), zero rows up to Tp (a multiple
+        of 256).  -> logits (B, vocab) float32 at each prompt's last position."""
+        c = self.cfg
+        B, Tp = len(lens), x.shape[0]
         cu_h = [0]
         for n in lens:
             cu_h.append(cu_h[-1] + n)

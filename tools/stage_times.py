@@ -34,12 +34,18 @@ for step in range(14):
     for n, a, b in zip(names, t[:-1], t[1:]):
         acc.setdefault(n, []).append((b - a) * 1e3)
     # LM on a fresh full build (state already advanced -> use the logits path of the NEXT frame separately)
+from dynam3d_amd.profiling import TIMER
+TIMER.enabled = True
+TIMER.reset()
 for step in range(3):
     fr = ep.next()
     obs = dict(rgb=torch.from_numpy(fr.rgb).to(dev), depth=torch.from_numpy(fr.depth).to(dev))
     pos, hd = [p.tolist() for p in fr.positions], list(fr.headings)
-    t0 = sync(); rows, L = net.build_inputs(obs, instr, pos, hd, patch_segm=fr.patch_segm, return_rows=True); t1 = sync()
-    lo = net.llm.prefill_logits_rows(rows); t2 = sync()
+    t0 = sync(); x, L = net.build_inputs(obs, instr, pos, hd, patch_segm=fr.patch_segm, return_rows="packed"); t1 = sync()
+    lo = net.llm.prefill_logits_packed(x, L); t2 = sync()
     acc.setdefault("build_inputs_total", []).append((t1 - t0) * 1e3); acc.setdefault("phi3_prefill", []).append((t2 - t1) * 1e3)
 for k, v in acc.items():
     print(f"{k:20s} {sum(v) / len(v):8.2f} ms   {['%.1f' % x for x in v]}")
+torch.cuda.synchronize()
+for k, (n, ms) in sorted(TIMER.summary().items()):
+    print(f"  event-timed {k:22s} {ms:8.3f} ms  x{n // 3} per step")
