@@ -13,13 +13,18 @@ def run_case(name, ops, device, on_step=None):
     case = TRAJ_CASES[name]
     g = load(f"g4_{name}.npz")
     sd = synth_state_dict(ff_param_spec(), seed=0)
-    ff = Feature_Fields(case["B"], device=device, state_dict=sd, ops=ops, max_steps=case["steps"] + 1)
+    ff = Feature_Fields(case["B"], device=device, state_dict=sd, ops=ops, max_steps=(case["steps"] + 1) * case.get("views", 1))
     ff.initialize_camera_setting(90.0, 90.0)
+    V = case.get("views", 1)
     for t, inp in enumerate(traj_inputs(case)):
-        ff.delete_old_features_from_camera_frustum(torch.from_numpy(inp["depth_full"]), inp["positions"], inp["headings"])
-        ff.update_feature_fields(inp["depth24"], inp["grid"], None, inp["positions"], inp["headings"], patch_segm=inp["patch_segm"])
+        if case.get("pop") and case["pop"][0] == t:
+            ff.pop(case["pop"][1])
+        ff.delete_old_features_from_camera_frustum(torch.from_numpy(inp["depth_full"]), inp["positions"], inp["headings"], num_of_views=V)
+        ff.update_feature_fields(inp["depth24"], inp["grid"], None, inp["positions"], inp["headings"], num_of_views=V,
+                                 patch_segm=inp["patch_segm"])
         ev = ff.get_environment_features(inp["positions"], inp["headings"])
-        for b in range(case["B"]):
+        assert ff.batch_size == len(inp["alive"])
+        for b in range(ff.batch_size):
             ex = ff.export_env(b)
             env = dict(irel=ev["batch_instance_relative_position"][b].cpu().numpy(), zrel=ev["batch_zone_relative_position"][b].cpu().numpy(),
                        ifts=ev["batch_instance_fts"][b].cpu().numpy(), zfts=ev["batch_zone_fts"][b].cpu().numpy())

@@ -130,10 +130,15 @@ def g4_trajectories():
         B, steps = case["B"], case["steps"]
         ref = rh.RefFeatureFields(B, sd)
         out = {"B": np.int64(B), "steps": np.int64(steps)}
+        V = case.get("views", 1)
         for t, inp in enumerate(traj_inputs(case)):
+            if case.get("pop") and case["pop"][0] == t:
+                ref.F.pop(case["pop"][1])                       # the reference's own pop (VLN-FF:219-243)
+                B = ref.F.batch_size
             er = ref.step(torch.from_numpy(inp["depth_full"]), inp["depth24"], inp["grid"], torch.from_numpy(inp["patch_segm"]),
-                          inp["positions"], inp["headings"])
+                          inp["positions"], inp["headings"], num_of_views=V)
             F = ref.F
+            out[f"t{t}_B"] = np.int64(B)
             for b in range(B):
                 p = f"t{t}_b{b}_"
                 own = F.global_patch_to_instance_dict[b]
@@ -161,7 +166,7 @@ def g4_trajectories():
                     out[p + short] = er[k_][b].numpy().copy()
                 out[p + "env_ifts_head"] = er["batch_instance_fts"][b].numpy()[:, :16].copy()
                 out[p + "env_zfts_head"] = er["batch_zone_fts"][b].numpy()[:, :16].copy()
-            print(name, "step", t, [len(F.global_instance_to_patch_dict[b]) for b in range(B)])
+            print(name, "step", t, [len(F.global_instance_to_patch_dict[b]) for b in range(B)], flush=True)
         np.savez_compressed(os.path.join(OUT, f"g4_{name}.npz"), **out)
     print("g4 ok")
 

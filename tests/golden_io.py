@@ -13,25 +13,37 @@ from oracle import geometry as G
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 TRAJ_CASES = {
-    # name: episode generator settings
+    # name: episode generator settings.  views > 1 = panorama (view ix looks along heading - ix*pi/6, VLN-FF:529-550);
+    # pop = (step, env): `Feature_Fields.pop(env)` is called BEFORE that step (an episode ended, VLN-TR:778-784) and the
+    # remaining environments carry on with their own streams.
     "walk": dict(B=2, steps=7, seed=1, grid_seed=5, stationary=False, wall=None, depth_hw=224),
     "wall": dict(B=2, steps=5, seed=2, grid_seed=6, stationary=True, wall=2.0, depth_hw=64),
+    "pano3": dict(B=2, steps=4, seed=3, grid_seed=7, stationary=False, wall=None, depth_hw=64, views=3),
+    "pop": dict(B=3, steps=5, seed=4, grid_seed=8, stationary=False, wall=None, depth_hw=64, pop=(3, 1)),
 }
 
 
 def traj_inputs(case):
-    B = case["B"]
-    ep = SyntheticEpisodes(B, seed=case["seed"], stationary=case["stationary"], wall=case["wall"],
-                           depth_hw=case["depth_hw"], image_hw=32)
+    """Yields one dict per step for the environments still alive (see `pop`): depth_full (B,V,H,W), depth24 (B,V,576),
+    grid (B,V,576,768), patch_segm (B*V,1,24,24) environment-major, positions, headings."""
+    B0, V = case["B"], case.get("views", 1)
+    eps = [SyntheticEpisodes(B0, seed=case["seed"] + 100 * v, stationary=case["stationary"], wall=case["wall"],
+                             depth_hw=case["depth_hw"], image_hw=32) for v in range(V)]
     rng = np.random.default_rng(case["grid_seed"])
-    for _ in range(case["steps"]):
-        fr = ep.next()
-        dfull = G.preprocess_depth(fr.depth)[..., 0]
-        d24 = G.preprocess_depth(G.downsample_depth_nearest(fr.depth)).reshape(B, 1, 576)
-        grid = rng.standard_normal((B, 1, 576, 768)).astype(np.float32)
-        yield dict(depth_full=dfull.reshape(B, 1, *dfull.shape[1:]).copy(), depth24=d24, grid=grid,
-                   patch_segm=fr.patch_segm, positions=[p.tolist() for p in fr.positions], headings=list(fr.headings),
-                   depth_raw=fr.depth, rgb=fr.rgb)
+    alive = list(range(B0))
+    for t in range(case["steps"]):
+        if case.get("pop") and case["pop"][0] == t:
+            alive.pop(case["pop"][1])
+        frs = [ep.next() for ep in eps]
+        grid_all = rng.standard_normal((B0, V, 576, 768)).astype(np.float32)
+        idx = np.asarray(alive)
+        dfull = np.stack([G.preprocess_depth(fr.depth)[..., 0] for fr in frs], 1)[idx]                      # (B,V,H,W)
+        d24 = np.stack([G.preprocess_depth(G.downsample_depth_nearest(fr.depth)).reshape(B0, 576) for fr in frs], 1)[idx]
+        segm = np.stack([fr.patch_segm for fr in frs], 1)[idx]                                              # (B,V,1,24,24)
+        fr = frs[0]
+        yield dict(depth_full=dfull.copy(), depth24=d24.copy(), grid=grid_all[idx].copy(),
+                   patch_segm=segm.reshape(len(alive) * V, *segm.shape[2:]).copy(), positions=[fr.positions[i].tolist() for i in alive],
+                   headings=[fr.headings[i] for i in alive], depth_raw=fr.depth[idx], rgb=fr.rgb[idx], alive=list(alive))
 
 
 def pack_ragged(arrs):

@@ -91,10 +91,14 @@ def test_g4_trajectory(name):
     g = load(f"g4_{name}.npz")
     sd = synth_state_dict(ff_param_spec(), seed=0)
     orc = FeatureFieldsOracle(sd, case["B"])
+    V = case.get("views", 1)
     for t, inp in enumerate(traj_inputs(case)):
-        orc.delete_old_features_from_camera_frustum(inp["depth_full"], inp["positions"], inp["headings"])
-        orc.update_feature_fields(inp["depth24"], inp["grid"], inp["patch_segm"], inp["positions"], inp["headings"])
+        if case.get("pop") and case["pop"][0] == t:
+            orc.pop(case["pop"][1])
+        orc.delete_old_features_from_camera_frustum(inp["depth_full"], inp["positions"], inp["headings"], num_of_views=V)
+        orc.update_feature_fields(inp["depth24"], inp["grid"], inp["patch_segm"], inp["positions"], inp["headings"], num_of_views=V)
         ev = orc.get_environment_features(inp["positions"], inp["headings"])
+        assert len(orc.env) == len(inp["alive"])
         for b, e in enumerate(orc.env):
             env = dict(irel=ev["batch_instance_relative_position"][b], zrel=ev["batch_zone_relative_position"][b],
                        ifts=ev["batch_instance_fts"][b], zfts=ev["batch_zone_fts"][b])
