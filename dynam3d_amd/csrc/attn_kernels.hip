@@ -88,7 +88,7 @@ template <bool BF16, int HD, bool CAUSAL>
 __global__ void __launch_bounds__(NT, 2)          // 2 waves/SIMD = 2 workgroups per CU: keep VGPR+AGPR <= 256
 k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, int Sp, uint16_t* __restrict__ out, int S, int H,
              int64_t row_stride /* elements between tokens */, int64_t batch_stride, int q_off, int k_off, float scale_log2e, int seq_len,
-             const int32_t* __restrict__ cu /* packed batch: (B+1) row offsets, or null */) {
+             const int32_t* __restrict__ cu /* packed batch: (B+1) row offsets, or null */, int n_qblocks) {
     // K rows are padded to a power-of-two number of 16-byte chunks and XOR-swizzled (chunk ^= row & (KCH-1)): every
     // ds_read_b128 lane group (which mixes two k-groups, e.g. lanes {0-3,12-15,20-27}) then hits 16 distinct slots.
     constexpr int KCH = HD == 96 ? 16 : 8;   // chunk positions per LDS row
@@ -102,8 +102,18 @@ k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
-    // causal: late query blocks have the most key tiles -> dispatch them first so the short ones fill the tail
-    const int qb = CAUSAL ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // Query blocks.  CAUSAL: a workgroup takes the PAIR (n-1-x, x) -- the longest block with the shortest, and so on -- so that
+    // every workgroup walks the same number of key tiles (2x+2 + 2(n-1-x)+2); one block per workgroup left the last
+    // rounds to whatever lengths came last.  The pair index is rotated by head + batch: workgroups go to the 8 XCDs
+    // round-robin by linear id, and without the rotation one XCD would receive every workgroup of one x.
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int xq = (int)((blockIdx.x + blockIdx.y + blockIdx.z) % gridDim.x);
+    const int S_in = S, seq_len_in = seq_len;
+  for (int pass = 0; pass < (CAUSAL ? 2 : 1); ++pass) {
+    const int qb = CAUSAL ? (pass == 0 ? n_qblocks - 1 - xq : xq) : xq;
+    if (CAUSAL && pass == 1 && qb == n_qblocks - 1 - xq) break;          // odd count: the middle block stands alone
+    S = S_in;
+    seq_len = seq_len_in;
     const int q0 = qb * BQ, qw = q0 + wave * 32;
     int64_t row0 = (int64_t)b * S;                         // first output row of this sequence
     const uint16_t* base = qkv + (int64_t)b * batch_stride;
@@ -111,7 +121,7 @@ k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, 
         row0 = cu[b];
         S = cu[b + 1] - cu[b];
         seq_len = S;
-        if (q0 >= S) return;                               // (uniform) query block beyond this sequence
+        if (q0 >= S) continue;                             // (uniform) query block beyond this sequence
         base = qkv + row0 * row_stride;
     }
     const uint16_t* Qp = base + (int64_t)(q_off + h) * HD;
@@ -292,6 +302,7 @@ k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, 
             *reinterpret_cast<uint2*>(op + dt * 16 + fg * 4) = o;
         }
     }
+  }   // pass
 }
 
 }  // namespace
@@ -321,8 +332,9 @@ int32_t d3d_flash_attention(const void* qkv, void* out, void* vt_scratch, int32_
     dim3 tg(Sp / 64, H, B);
     if (head_dim == 96) hipLaunchKernelGGL(k_transpose_v<96>, tg, dim3(256), 0, s, q, vt, S, Sp, H, row_stride, batch_stride, v_off, cu_seqlens);
     else hipLaunchKernelGGL(k_transpose_v<64>, tg, dim3(256), 0, s, q, vt, S, Sp, H, row_stride, batch_stride, v_off, cu_seqlens);
-    dim3 grid((S + BQ - 1) / BQ, H, B), block(NT);
-#define D3D_FA(BF, HDV, CA) hipLaunchKernelGGL((k_flash_attn<BF, HDV, CA>), grid, block, 0, s, q, vt, Sp, o, S, H, row_stride, batch_stride, q_off, k_off, sl2, seq_len, cu_seqlens)
+    const int nqb = (S + BQ - 1) / BQ;
+    dim3 grid(causal ? (nqb + 1) / 2 : nqb, H, B), block(NT);            // causal: one workgroup per PAIR of query blocks
+#define D3D_FA(BF, HDV, CA) hipLaunchKernelGGL((k_flash_attn<BF, HDV, CA>), grid, block, 0, s, q, vt, Sp, o, S, H, row_stride, batch_stride, q_off, k_off, sl2, seq_len, cu_seqlens, nqb)
     if (dtype == 0) {
         if (head_dim == 96) { if (causal) D3D_FA(true, 96, true); else D3D_FA(true, 96, false); }
         else { if (causal) D3D_FA(true, 64, true); else D3D_FA(true, 64, false); }
