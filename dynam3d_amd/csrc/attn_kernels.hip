@@ -108,22 +108,20 @@ k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, 
     // round-robin by linear id, and without the rotation one XCD would receive every workgroup of one x.
     const int h = blockIdx.y, b = blockIdx.z;
     const int xq = (int)((blockIdx.x + blockIdx.y + blockIdx.z) % gridDim.x);
-    const int S_in = S, seq_len_in = seq_len;
-  for (int pass = 0; pass < (CAUSAL ? 2 : 1); ++pass) {
-    const int qb = CAUSAL ? (pass == 0 ? n_qblocks - 1 - xq : xq) : xq;
-    if (CAUSAL && pass == 1 && qb == n_qblocks - 1 - xq) break;          // odd count: the middle block stands alone
-    S = S_in;
-    seq_len = seq_len_in;
-    const int q0 = qb * BQ, qw = q0 + wave * 32;
     int64_t row0 = (int64_t)b * S;                         // first output row of this sequence
     const uint16_t* base = qkv + (int64_t)b * batch_stride;
-    if (cu) {
+    if (cu) {                                              // packed batch: this sequence's own length and block count
         row0 = cu[b];
         S = cu[b + 1] - cu[b];
         seq_len = S;
-        if (q0 >= S) continue;                             // (uniform) query block beyond this sequence
+        n_qblocks = (S + BQ - 1) / BQ;
         base = qkv + row0 * row_stride;
     }
+    if (CAUSAL ? xq >= (n_qblocks + 1) / 2 : xq >= n_qblocks) return;   // (uniform) beyond this sequence
+  for (int pass = 0; pass < (CAUSAL ? 2 : 1); ++pass) {
+    const int qb = CAUSAL ? (pass == 0 ? n_qblocks - 1 - xq : xq) : xq;
+    if (CAUSAL && pass == 1 && qb == n_qblocks - 1 - xq) break;          // odd count: the middle block stands alone
+    const int q0 = qb * BQ, qw = q0 + wave * 32;
     const uint16_t* Qp = base + (int64_t)(q_off + h) * HD;
     const uint16_t* Kp = base + (int64_t)(k_off + h) * HD;
     const uint16_t* Vtp = vt + (((int64_t)b * H + h) * HD) * Sp;          // (hd, Sp) key-major
