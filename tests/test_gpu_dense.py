@@ -178,3 +178,27 @@ def test_flash_attention_vs_fp32_reference(hd, dt, tol):
     q, k, v = (qkv[:, :, i * H:(i + 1) * H].transpose(1, 2).float() for i in range(3))
     ref = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2)
     assert rel(hd.attention_qkv(qkv, H, True).float(), ref) < tol
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 6e-3), (torch.float16, 1e-3)])
+def test_flash_attention_packed_ragged(hd, dt, tol, causal):
+    """Packed variable-length batch (cu_seqlens): sequences of 1 token, below / at / just above a 128-row query block and a
+    64-key tile, odd and even block counts (the causal kernel pairs the longest block of a sequence with its shortest), padding
+    rows after the last sequence.  Reference: fp32 softmax attention per sequence.  Tolerance = 16-bit output rounding + 16-bit P."""
+    torch.manual_seed(5)
+    H, d = 4, 96
+    lens = [1, 63, 128, 129, 200, 385, 640, 705]
+    T = sum(lens)
+    Tp = (T + 255) // 256 * 256
+    qkv = (torch.randn(Tp, 3 * H, d, device="cuda") * 0.8).to(dt)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    out = hd.attention_packed(qkv, H, causal, cu, len(lens), max(lens)).float()
+    o = 0
+    for n in lens:
+        x = qkv[o:o + n].float()
+        q, k, v = x[:, :H].transpose(0, 1), x[:, H:2 * H].transpose(0, 1), x[:, 2 * H:].transpose(0, 1)      # (H,n,d)
+        ref = F.scaled_dot_product_attention(q[None], k[None], v[None], is_causal=causal)[0].transpose(0, 1)
+        assert rel(out[o:o + n], ref) < tol, (n, rel(out[o:o + n], ref))
+        o += n
+    assert float(out[T:].abs().max()) == 0.0                     # padding rows untouched
