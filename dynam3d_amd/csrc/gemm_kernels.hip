@@ -583,6 +583,18 @@ inline void split_plan(int tiles, int nk, int* dp_tiles, int* splits) {
     *splits = sp < 1 ? 1 : sp;
 }
 
+bool split_stream_ok(hipStream_t s) {
+    static std::mutex mu;
+    static bool owned = false;
+    static hipStream_t owner = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!owned) {
+        owned = true;
+        owner = s;
+    }
+    return owner == s;
+}
+
 template <bool BF16, int EPI>
 int32_t launch256_split(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
                         int64_t ldw, int64_t ldc, hipStream_t s) {
@@ -590,6 +602,10 @@ int32_t launch256_split(const void* A, const void* W, void* C, const void* bias,
     int dp_tiles, splits;
     split_plan(tiles, K / BK, &dp_tiles, &splits);
     if (splits < 2) return launch256<BF16, EPI, true>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s);
+    // The sibling wait needs every slice of a launch's tail resident at once (tail * splits <= CUs, one workgroup per CU).  Two
+    // such launches running CONCURRENTLY on different streams could each hold half the chip while waiting for the other half,
+    // so only one stream per process -- the first that asks -- gets the split path; any other stream runs the unsplit kernel.
+    if (!split_stream_ok(s)) return launch256<BF16, EPI, true>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s);
     const int tail = tiles - dp_tiles;
     SplitWorkspace* w = nullptr;
     int32_t rc = split_workspace(s, cu_count(), &w);

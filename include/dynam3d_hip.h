@@ -169,7 +169,8 @@ int32_t d3d_gemm_nt(const void* A_d, const void* W_d, void* C_d, const void* bia
                     void* stream);
 /* same with an explicit tile: 128 = 128x128x64 (4 waves, 2 workgroups/CU), 256 / 257 = 256x256x64 staggered wave groups
  * stepping K-halves / whole K tiles, 258 = 257 with the partial last round of tiles split along K (fp32 partials in a
- * library-owned per-stream workspace, deterministic reduction); d3d_gemm_nt picks one (and splits the M remainder) itself.
+ * library-owned per-stream workspace, deterministic reduction; taken on ONE stream per process -- the first that asks --
+ * because its slices wait for each other on the device); d3d_gemm_nt picks one (and splits the M remainder) itself.
  * epilogue 7 = LeakyReLU(0.01) for the tcnn CutlassMLP replacement. */
 int32_t d3d_gemm_nt_tile(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
                          int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
