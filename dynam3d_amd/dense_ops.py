@@ -106,8 +106,8 @@ def rope_packed_(qkv2d: torch.Tensor, n_rot_heads: int, head_dim: int, cos, sin,
     return qkv2d
 
 
-def attention_packed(qkv3: torch.Tensor, n_heads: int, causal: bool, cu_seqlens: torch.Tensor, n_seq: int, max_len: int):
-    return _hip.attention_packed(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len)
+def attention_packed(qkv3: torch.Tensor, n_heads: int, causal: bool, cu_seqlens: torch.Tensor, n_seq: int, max_len: int, n_valid=None):
+    return _hip.attention_packed(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid)
 
 
 def rope_qk_(qkv: torch.Tensor, n_rot_heads: int, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:

@@ -151,11 +151,16 @@ class HipDense:
                                                 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
         return out
 
-    def attention_packed(self, qkv, n_heads, causal, cu_seqlens, n_seq, max_len):
+    def attention_packed(self, qkv, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid=None):
         """PACKED variable-length batch: qkv (T, 3H, hd) rows of sequence b = [cu[b], cu[b+1]) -> (T, H, hd).  Rows beyond
-        cu[-1] (padding of the packed buffer) are left untouched."""
+        cu[-1] (padding of the packed buffer) come back zero; `n_valid` = cu[-1] as a host int saves zero-filling the rest."""
         T, Ht, hd = qkv.shape
-        out = torch.zeros((T, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
+        if n_valid is None:
+            out = torch.zeros((T, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
+        else:
+            out = torch.empty((T, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
+            if n_valid < T:
+                out[n_valid:].zero_()
         vt = torch.empty((n_seq, n_heads, hd, (max_len + 63) // 64 * 64), dtype=qkv.dtype, device=qkv.device)
         _lib.check(self.lib.d3d_flash_attention(_p(qkv), _p(out), _p(vt), n_seq, max_len, n_heads, hd, Ht * hd, 0, 0, n_heads, 2 * n_heads,
                                                 1 if causal else 0, max_len, _p(cu_seqlens), 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))

@@ -300,7 +300,7 @@ class Phi3Decoder:
             h = D.rms_norm(x, L["n1"], c.rms_eps)
             qkv = D.linear(h, L["qkv_w"], None)
             D.rope_packed_(qkv, c.heads + c.kv_heads, c.head_dim, cos, sin, pos)
-            a = D.attention_packed(qkv.view(Tp, Ht, c.head_dim), c.heads, True, cu, B, max_len)
+            a = D.attention_packed(qkv.view(Tp, Ht, c.head_dim), c.heads, True, cu, B, max_len, n_valid=cu_h[-1])
             x = D.linear(a.view(Tp, c.heads * c.head_dim), L["o_w"], None, residual=x)
             h = D.rms_norm(x, L["n2"], c.rms_eps)
             with TIMER.range("phi3.gate_up_proj"):
