@@ -303,6 +303,120 @@ k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, 
   }   // pass
 }
 
+// ================================================================================================
+// Decode attention (KV cache): ONE query token per sequence against that sequence's prompt keys/values, read in place from the
+// prefill's post-RoPE fused-QKV buffer of the layer (packed rows cu[b] .. cu[b+1]), plus the tokens generated so far, kept
+// in a small side cache (B, Tmax, H, hd).  The current token's own k/v rows (already rotated, in `qkv_new`) are appended to
+// the side cache by this kernel.  One workgroup per (head, sequence): threads own keys for the scores, a block softmax in
+// LDS, then waves own key subsets and lanes own head-dim pairs for the weighted value sum.  Reference: the `use_cache`
+// branch of HF Phi-3 attention under `llava.generate(..., do_sample=False)` (VLN-POL:463).
+// ================================================================================================
+template <bool BF16>
+__device__ __forceinline__ float cvt16(uint16_t v) {
+    if constexpr (BF16) return __uint_as_float((uint32_t)v << 16);
+    else return __half2float(*reinterpret_cast<const __half*>(&v));
+}
+
+constexpr int DEC_MAX_KEYS = 4096 + 64;
+
+template <bool BF16, int HD>
+__global__ void __launch_bounds__(256)
+k_decode_attn(const uint16_t* __restrict__ qkv_new /* (B, 3H, HD): this step's rotated q,k and v */, const uint16_t* __restrict__ prompt /* (T, 3H, HD) */,
+              const int32_t* __restrict__ cu, uint16_t* __restrict__ knew, uint16_t* __restrict__ vnew /* (B, Tmax, H, HD) */,
+              uint16_t* __restrict__ out /* (B, H, HD) */, int H, int t_new, int Tmax, float scale) {
+    __shared__ float qs[HD];
+    __shared__ float sc[DEC_MAX_KEYS];
+    __shared__ float red[8];
+    __shared__ float part[4][HD];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t rs = (int64_t)3 * H * HD;                                   // fused row stride (elements)
+    const int r0 = cu[b], S = cu[b + 1] - r0, L = S + t_new + 1;               // prompt keys + generated (incl. the current one)
+    const uint16_t* qrow = qkv_new + (int64_t)b * rs + (int64_t)h * HD;
+    // append the current token's k / v to the side cache (first HD*2/8 threads copy 16 bytes each)
+    if (tid < 2 * HD / 8) {
+        const int which = tid / (HD / 8), c = tid % (HD / 8);
+        const uint4 v = *reinterpret_cast<const uint4*>(qrow + (int64_t)(which + 1) * H * HD + c * 8);
+        uint16_t* dst = (which == 0 ? knew : vnew) + (((int64_t)b * Tmax + t_new) * H + h) * HD + c * 8;
+        *reinterpret_cast<uint4*>(dst) = v;
+    }
+    if (tid < HD) qs[tid] = cvt16<BF16>(qrow[tid]) * scale;
+    __syncthreads();
+    // key j: prompt row | earlier generated token (side cache, written by EARLIER launches) | the current token, read from
+    // qkv_new itself so that nothing written by this launch is read back by it
+    auto krow = [&](int j) -> const uint16_t* {
+        if (j < S) return prompt + (int64_t)(r0 + j) * rs + (int64_t)(H + h) * HD;
+        if (j == L - 1) return qrow + (int64_t)H * HD;
+        return knew + (((int64_t)b * Tmax + (j - S)) * H + h) * HD;
+    };
+    auto vrow = [&](int j) -> const uint16_t* {
+        if (j < S) return prompt + (int64_t)(r0 + j) * rs + (int64_t)(2 * H + h) * HD;
+        if (j == L - 1) return qrow + (int64_t)2 * H * HD;
+        return vnew + (((int64_t)b * Tmax + (j - S)) * H + h) * HD;
+    };
+    // ---- scores: thread-per-key dot products (four partial sums), running max
+    float tmax = -INFINITY;
+    for (int j = tid; j < L; j += 256) {
+        const uint16_t* kp = krow(j);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD / 8; ++c) {
+            const uint4 kv = *reinterpret_cast<const uint4*>(kp + c * 8);
+            const uint16_t* e = reinterpret_cast<const uint16_t*>(&kv);
+            s0 += qs[c * 8 + 0] * cvt16<BF16>(e[0]) + qs[c * 8 + 4] * cvt16<BF16>(e[4]);
+            s1 += qs[c * 8 + 1] * cvt16<BF16>(e[1]) + qs[c * 8 + 5] * cvt16<BF16>(e[5]);
+            s2 += qs[c * 8 + 2] * cvt16<BF16>(e[2]) + qs[c * 8 + 6] * cvt16<BF16>(e[6]);
+            s3 += qs[c * 8 + 3] * cvt16<BF16>(e[3]) + qs[c * 8 + 7] * cvt16<BF16>(e[7]);
+        }
+        const float sdot = (s0 + s1) + (s2 + s3);
+        sc[j] = sdot;
+        tmax = fmaxf(tmax, sdot);
+    }
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, w, 64));
+    if (lane == 0) red[wave] = tmax;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.f;
+    for (int j = tid; j < L; j += 256) {
+        const float p = __expf(sc[j] - m);
+        sc[j] = p;
+        lsum += p;
+    }
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) lsum += __shfl_xor(lsum, w, 64);
+    if (lane == 0) red[4 + wave] = lsum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    // ---- O = P V: wave w takes keys w, w+4, ...; lane l < HD/2 owns head-dim elements 2l, 2l+1 (one 4-byte load per key)
+    float o0 = 0.f, o1 = 0.f;
+    if (lane < HD / 2) {
+        int j = wave;
+        for (; j + 12 < L; j += 16) {                                          // four keys in flight
+            const uint32_t v0 = *reinterpret_cast<const uint32_t*>(vrow(j) + 2 * lane);
+            const uint32_t v1 = *reinterpret_cast<const uint32_t*>(vrow(j + 4) + 2 * lane);
+            const uint32_t v2 = *reinterpret_cast<const uint32_t*>(vrow(j + 8) + 2 * lane);
+            const uint32_t v3 = *reinterpret_cast<const uint32_t*>(vrow(j + 12) + 2 * lane);
+            const float p0 = sc[j], p1 = sc[j + 4], p2 = sc[j + 8], p3 = sc[j + 12];
+            o0 += (p0 * cvt16<BF16>((uint16_t)v0) + p1 * cvt16<BF16>((uint16_t)v1)) + (p2 * cvt16<BF16>((uint16_t)v2) + p3 * cvt16<BF16>((uint16_t)v3));
+            o1 += (p0 * cvt16<BF16>((uint16_t)(v0 >> 16)) + p1 * cvt16<BF16>((uint16_t)(v1 >> 16))) +
+                  (p2 * cvt16<BF16>((uint16_t)(v2 >> 16)) + p3 * cvt16<BF16>((uint16_t)(v3 >> 16)));
+        }
+        for (; j < L; j += 4) {
+            const uint32_t v0 = *reinterpret_cast<const uint32_t*>(vrow(j) + 2 * lane);
+            o0 += sc[j] * cvt16<BF16>((uint16_t)v0);
+            o1 += sc[j] * cvt16<BF16>((uint16_t)(v0 >> 16));
+        }
+        part[wave][2 * lane] = o0;
+        part[wave][2 * lane + 1] = o1;
+    }
+    __syncthreads();
+    if (tid < HD / 2) {
+        const float a0 = ((part[0][2 * tid] + part[1][2 * tid]) + (part[2][2 * tid] + part[3][2 * tid])) * inv;
+        const float a1 = ((part[0][2 * tid + 1] + part[1][2 * tid + 1]) + (part[2][2 * tid + 1] + part[3][2 * tid + 1])) * inv;
+        *reinterpret_cast<uint32_t*>(out + ((int64_t)b * H + h) * HD + 2 * tid) = pack2<BF16>(a0, a1);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -343,5 +457,27 @@ int32_t d3d_flash_attention(const void* qkv, void* out, void* vt_scratch, int32_
 #undef D3D_FA
     D3D_LAUNCH_CHECK();
 }
+
+// One decode step of causal self-attention with a KV cache (see k_decode_attn).  qkv_new: (B, 3H, hd) this step's fused projection
+// AFTER RoPE; prompt_qkv: the layer's prefill buffer (packed rows, post-RoPE) with cu_seqlens (B+1); knew / vnew: (B, Tmax, H, hd)
+// side caches, filled for tokens < t_new by earlier calls -- this call appends token t_new.  out: (B, H, hd).
+int32_t d3d_decode_attention(const void* qkv_new, const void* prompt_qkv, const int32_t* cu_seqlens, void* knew, void* vnew, void* out, int32_t B,
+                             int32_t H, int32_t head_dim, int32_t t_new, int32_t Tmax, int32_t max_prompt_len, int32_t dtype, void* stream) {
+    if (B <= 0) return D3D_OK;
+    if ((head_dim != 64 && head_dim != 96) || t_new < 0 || t_new >= Tmax || max_prompt_len + Tmax > DEC_MAX_KEYS) {
+        d3d_set_error_("d3d_decode_attention: head_dim must be 64 or 96, 0 <= t_new < Tmax, prompt + Tmax <= 4160 keys");
+        return D3D_EINVAL;
+    }
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    dim3 grid(H, B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define D3D_DEC(BF, HDV) hipLaunchKernelGGL((k_decode_attn<BF, HDV>), grid, block, 0, s, (const uint16_t*)qkv_new, (const uint16_t*)prompt_qkv, cu_seqlens, \
+                                            (uint16_t*)knew, (uint16_t*)vnew, (uint16_t*)out, H, t_new, Tmax, scale)
+    if (dtype == 0) { if (head_dim == 96) D3D_DEC(true, 96); else D3D_DEC(true, 64); }
+    else { if (head_dim == 96) D3D_DEC(false, 96); else D3D_DEC(false, 64); }
+#undef D3D_DEC
+    D3D_LAUNCH_CHECK();
+}
+
 
 }  // extern "C"

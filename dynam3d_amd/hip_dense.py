@@ -19,6 +19,7 @@ _lib.register("d3d_set_attention", [vp, vp, i32, i32, i32, i32, vp, vp])
 _lib.register("d3d_flash_attention", [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp])
 _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
 _lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
+_lib.register("d3d_decode_attention", [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -114,6 +115,16 @@ class HipDense:
         """qkv2d (rows, >= n_rot_heads*hd) bf16/fp16, rotated in place; position = pos[row] if given else row % S."""
         _lib.check(self.lib.d3d_rope_inplace(_p(qkv2d), _p(cos), _p(sin), qkv2d.shape[0], S, n_rot_heads, hd, qkv2d.stride(0), _p(pos),
                                              0 if qkv2d.dtype == torch.bfloat16 else 1, self._stream()))
+
+    def decode_attention(self, qkv_new, prompt_qkv, cu_seqlens, knew, vnew, n_heads, t_new, max_prompt_len):
+        """One KV-cache decode step: qkv_new (B, 3H*hd) rotated; prompt_qkv (T, 3H*hd) the layer's prefill buffer; knew / vnew
+        (B, Tmax, H, hd) side caches (token t_new is appended here).  -> (B, H*hd)."""
+        B = qkv_new.shape[0]
+        Tmax, hd = knew.shape[1], knew.shape[3]
+        out = torch.empty((B, n_heads * hd), dtype=qkv_new.dtype, device=qkv_new.device)
+        _lib.check(self.lib.d3d_decode_attention(_p(qkv_new), _p(prompt_qkv), _p(cu_seqlens), _p(knew), _p(vnew), _p(out), B, n_heads, hd, t_new, Tmax,
+                                                 max_prompt_len, 0 if qkv_new.dtype == torch.bfloat16 else 1, self._stream()))
+        return out
 
     def resize_normalize(self, rgb_u8, size, mean, std):
         import numpy as np

@@ -283,11 +283,17 @@ class Dynam3D_VLN:
     @torch.no_grad()
     def forward(self, observations, instructions, agent_positions, agent_heading_angles, depth_scale=(0.0, 10.0), gt_text=None,
                 delete_old_features=True, num_of_views=1, is_train=False, patch_segm=None, max_new_tokens: int = 20):
-        """Eval branch of VLN-POL:430-469: greedy text generation + per-row history update.  The decode loop
-        recomputes the prefix each token (no KV cache yet -- SURVEY.md 8f-4); the benchmarked metric is
-        `forward_logits`."""
+        """Eval branch of VLN-POL:430-469: greedy text generation + per-row history update.  On the HIP backend the prompt
+        is prefilled once (packed) and every further token is an 8-row pass over a KV cache (`Phi3Decoder.generate_packed`,
+        SURVEY.md 8f-4); elsewhere (CPU tests) the prefix is recomputed per token.  The headline metric is `forward_logits`."""
         if is_train:
             raise NotImplementedError("training branch (loss over gt_text) is outside the hot path: SURVEY.md 8f-1")
+        end_id = self.tokenizer.SPECIAL["<|end|>"] % self.cfg.llm.vocab
+        if self.llm.packed_ok() and self.cfg.llm.kv_heads == self.cfg.llm.heads:
+            x, lengths = self.build_inputs(observations, instructions, agent_positions, agent_heading_angles, depth_scale,
+                                           delete_old_features, num_of_views, patch_segm, return_rows="packed")
+            gen = self.llm.generate_packed(x, lengths, max_new_tokens=max_new_tokens, end_id=end_id)       # KV-cache decode
+            return self._finish_generation(gen)
         embeds, lengths = self.build_inputs(observations, instructions, agent_positions, agent_heading_angles, depth_scale,
                                             delete_old_features, num_of_views, patch_segm)
         B = embeds.shape[0]
@@ -309,8 +315,11 @@ class Dynam3D_VLN:
             lengths = lengths + torch.tensor([0 if d and len(g) and g[-1] != end_id else 1 for d, g in zip(done, gen)], device=self.device)
             if all(done):
                 break
+        return self._finish_generation(gen)
+
+    def _finish_generation(self, gen):
         texts = []
-        for b in range(B):
+        for b in range(len(gen)):
             t = self.tokenizer.decode(gen[b])
             cut = t.find("<|end|>")
             t = t[:cut] if cut >= 0 else t

@@ -280,9 +280,10 @@ class Phi3Decoder:
         return self.prefill_logits_packed(x, lens)
 
     @torch.no_grad()
-    def prefill_logits_packed(self, x: torch.Tensor, lens) -> torch.Tensor:
+    def prefill_logits_packed(self, x: torch.Tensor, lens, keep_kv: Optional[list] = None) -> torch.Tensor:
         """x (Tp, hidden) in the LM's dtype: the B prompts back to back (lens[b] rows each), zero rows up to Tp (a multiple
-        of 256).  -> logits (B, vocab) float32 at each prompt's last position."""
+        of 256).  -> logits (B, vocab) float32 at each prompt's last position.  `keep_kv`: a list that receives every layer's
+        fused-QKV buffer after RoPE -- the prompt part of the KV cache, read in place by `generate_packed`."""
         c = self.cfg
         B, Tp = len(lens), x.shape[0]
         cu_h = [0]
@@ -300,6 +301,8 @@ class Phi3Decoder:
             h = D.rms_norm(x, L["n1"], c.rms_eps)
             qkv = D.linear(h, L["qkv_w"], None)
             D.rope_packed_(qkv, c.heads + c.kv_heads, c.head_dim, cos, sin, pos)
+            if keep_kv is not None:
+                keep_kv.append(qkv)
             a = D.attention_packed(qkv.view(Tp, Ht, c.head_dim), c.heads, True, cu, B, max_len, n_valid=cu_h[-1])
             x = D.linear(a.view(Tp, c.heads * c.head_dim), L["o_w"], None, residual=x)
             h = D.rms_norm(x, L["n2"], c.rms_eps)
@@ -307,9 +310,54 @@ class Phi3Decoder:
                 act = D.linear_swiglu(h, L["gu_w"], self.interleave_gu)
             x = D.linear(act, L["down_w"], None, residual=x)
         self.last_packed_rows = Tp
+        self._last_cu = cu
         last = x[(cu[1:] - 1).long()]
         last = D.rms_norm(last, self.norm_w, c.rms_eps)
         return D.linear(last, self.lm_head_w, None).float()
+
+    @torch.no_grad()
+    def generate_packed(self, x: torch.Tensor, lens, max_new_tokens: int = 20, end_id: Optional[int] = None, forced=None,
+                        return_logits: bool = False):
+        """Greedy generation with a KV cache (`llava.generate(..., max_new_tokens=20, do_sample=False)`, VLN-POL:463).
+        Prefill as `prefill_logits_packed`; every later token costs one 8-row pass: the prompt keys/values are read in place
+        from the prefill's post-RoPE QKV buffers, the generated tokens' from a (B, max_new, H, hd) side cache per layer
+        (`d3d_decode_attention`).  Returns the token ids per sequence (up to and including `end_id`), and with
+        `return_logits` the (steps, B, vocab) float32 logits.  `forced` (steps x B ids) replaces the argmax (teacher forcing)."""
+        c = self.cfg
+        B = len(lens)
+        kv = []
+        logits = self.prefill_logits_packed(x, lens, keep_kv=kv)
+        cu = self._last_cu
+        H, hd = c.heads, c.head_dim
+        Tmax = max(1, max_new_tokens - 1)
+        side = torch.empty((c.layers, 2, B, Tmax, H, hd), dtype=self.dtype, device=self.device)
+        cos, sin = self._rope(max(lens) + max_new_tokens + 1)
+        lens_d = torch.tensor(lens, dtype=torch.int32, device=self.device)
+        gen, done, all_logits = [[] for _ in range(B)], [False] * B, []
+        for i in range(max_new_tokens):
+            if return_logits:
+                all_logits.append(logits)
+            nxt = logits.argmax(-1) if forced is None else torch.as_tensor(forced[i], device=self.device)
+            nxt_h = nxt.tolist()
+            for b in range(B):
+                if not done[b]:
+                    gen[b].append(int(nxt_h[b]))
+                    done[b] = end_id is not None and int(nxt_h[b]) == end_id
+            if i == max_new_tokens - 1 or all(done):
+                break
+            xt = self.embed_tokens(nxt.long()).to(self.dtype)                     # (B, hidden): generated token i at position lens + i
+            pos = lens_d + i
+            for li, L in enumerate(self.layers):
+                h = D.rms_norm(xt, L["n1"], c.rms_eps)
+                qkv = D.linear(h, L["qkv_w"], None)
+                D.rope_packed_(qkv, c.heads + c.kv_heads, hd, cos, sin, pos)
+                a = D.decode_attention(qkv, kv[li], cu, side[li, 0], side[li, 1], H, i, max(lens))
+                xt = D.linear(a, L["o_w"], None, residual=xt)
+                h = D.rms_norm(xt, L["n2"], c.rms_eps)
+                act = D.linear_swiglu(h, L["gu_w"], self.interleave_gu)
+                xt = D.linear(act, L["down_w"], None, residual=xt)
+            logits = D.linear(D.rms_norm(xt, self.norm_w, c.rms_eps), self.lm_head_w, None).float()
+        return (gen, torch.stack(all_logits)) if return_logits else gen
 
     @torch.no_grad()
     def prefill_logits(self, inputs_embeds: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:

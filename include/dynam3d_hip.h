@@ -175,6 +175,13 @@ int32_t d3d_gemm_nt(const void* A_d, const void* W_d, void* C_d, const void* bia
 int32_t d3d_gemm_nt_tile(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
                          int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
                          int32_t tile, void* stream);
+/* One decode step of causal self-attention with a KV cache -- the `use_cache` branch of the HF Phi-3 attention under
+ * `llava.generate(max_new_tokens=20, do_sample=False)` (VLN-POL:463).  qkv_new (B, 3H, hd): this step's fused projection after
+ * RoPE; prompt_qkv: the layer's prefill buffer (packed rows, post-RoPE) with cu_seqlens (B+1); knew / vnew (B, Tmax, H, hd): the
+ * generated tokens' keys / values -- this call appends token t_new and attends over prompt + tokens 0..t_new.  out (B, H, hd). */
+int32_t d3d_decode_attention(const void* qkv_new_d, const void* prompt_qkv_d, const int32_t* cu_seqlens_d, void* knew_d, void* vnew_d,
+                             void* out_d, int32_t B, int32_t H, int32_t head_dim, int32_t t_new, int32_t Tmax, int32_t max_prompt_len,
+                             int32_t dtype, void* stream);
 /* LayerNorm (rms = 0; clip/model.py:153-159: float32 statistics) or RMSNorm (rms = 1; Phi-3) over rows of D <= 4096 */
 int32_t d3d_norm(const void* x_d, const float* w_d, const float* b_d, void* y_d, int32_t rows, int32_t D, int64_t ldx,
                  int64_t ldy, float eps, int32_t rms, int32_t dtype, void* stream);

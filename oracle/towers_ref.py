@@ -142,6 +142,34 @@ def phi3_prefill_logits(embeds: T, lengths: Sequence[int], sd: Dict[str, T], lay
     return F.linear(rms(last, sd[m + "norm.weight"]), sd["language_model.lm_head.weight"].float())
 
 
+def phi3_greedy_decode(embeds: T, lengths: Sequence[int], sd: Dict[str, T], layers: int, heads: int, kv_heads: int, max_new_tokens: int,
+                       end_id=None, rms_eps: float = 1e-5, theta: float = 10000.0, forced=None):
+    """Greedy generation by DEFINITION -- `llava.generate(inputs_embeds=..., max_new_tokens=20, do_sample=False)` at VLN-POL:463
+    (transformers GenerationMixin greedy search, an un-vendored dependency): at every step the whole prefix is run again through
+    `phi3_prefill_logits` (no KV cache), the argmax token's embedding is appended to that sequence.  Small cases only.
+    Returns (tokens per sequence up to and including end_id, logits (steps,B,vocab)).  `forced` (steps x B) replaces the argmax."""
+    emb_w = sd["language_model.model.embed_tokens.weight"].float()
+    B, S, H = embeds.shape
+    emb = torch.zeros(B, S + max_new_tokens, H)
+    emb[:, :S] = embeds.float()
+    lens = [int(n) for n in lengths]
+    gen, done, steps = [[] for _ in range(B)], [False] * B, []
+    for i in range(max_new_tokens):
+        lo = phi3_prefill_logits(emb[:, : max(lens)], lens, sd, layers, heads, kv_heads, rms_eps, theta)
+        steps.append(lo)
+        nxt = lo.argmax(-1) if forced is None else torch.as_tensor(forced[i])
+        for b in range(B):
+            if not done[b]:
+                gen[b].append(int(nxt[b]))
+                done[b] = end_id is not None and int(nxt[b]) == end_id
+        if i == max_new_tokens - 1 or all(done):
+            break
+        for b in range(B):                                   # every sequence advances (finished ones are simply ignored afterwards)
+            emb[b, lens[b]] = emb_w[int(nxt[b])]
+            lens[b] += 1
+    return gen, torch.stack(steps)
+
+
 def prefix_tokens(info6: T, ifts: T, irel: T, zfts: T, zrel: T, sd: Dict[str, T]):
     """VLN-POL:432-435.  info6 (N,576,6) = [x,y,z,sin d,cos d,scale]."""
     f = {k: v.float() for k, v in sd.items() if k.split(".")[0] in ("patch_position_embedding", "instance_position_embedding",

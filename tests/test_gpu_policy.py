@@ -72,3 +72,79 @@ def test_rollout_driver_pops_finished_episodes():
     assert n == 3 and net.feature_fields.batch_size == 0
     res = DD.gather_metrics(sums, n, device="cuda")
     assert res["episodes"] == 3.0 and 1.0 <= res["steps_taken"] <= 5.0
+
+
+def test_phi3_kv_cache_generation_matches_oracle():
+    """Greedy generation with the KV cache (`Phi3Decoder.generate_packed`: prompt K/V read in place from the prefill buffers,
+    generated tokens in the side cache, `d3d_decode_attention`) vs the float32 oracle that re-runs the whole prefix for every
+    token (oracle/towers_ref.py::phi3_greedy_decode), on ragged prompts.  Teacher forcing with the oracle's tokens keeps both on
+    the same path: logits of every step within the bf16 tolerance of the prefill test; the free-running product must pick
+    the oracle's tokens wherever the oracle's top-2 margin is not within that tolerance, and stops at `end_id`."""
+    from dynam3d_amd import dense_ops as D
+    from dynam3d_amd.towers import Phi3Config, Phi3Decoder, phi3_param_spec
+    from dynam3d_amd.weights import synth_state_dict
+    from oracle import towers_ref as TR
+    cfg = Phi3Config(vocab=512, hidden=384, layers=2, heads=4, kv_heads=4, mlp=512)       # head_dim 96 like Phi-3-mini
+    sd = synth_state_dict(phi3_param_spec(cfg), seed=0)
+    lens = [37, 300, 129, 64]
+    steps = 6
+    g = torch.Generator().manual_seed(11)
+    rows = [(torch.randn(n, cfg.hidden, generator=g) * 0.5).to(torch.bfloat16) for n in lens]
+    emb = torch.zeros(len(lens), max(lens), cfg.hidden)
+    for b, r in enumerate(rows):
+        emb[b, :lens[b]] = r.float()
+    sd_r = {k: (v.to(torch.bfloat16).float() if v.dim() == 2 else v) for k, v in sd.items()}     # oracle on the same bf16 weights
+    ref_tok, ref_logits = TR.phi3_greedy_decode(emb, lens, sd_r, cfg.layers, cfg.heads, cfg.kv_heads, steps, None, cfg.rms_eps, cfg.rope_theta)
+    forced = [[ref_tok[b][i] for b in range(len(lens))] for i in range(steps)]
+    saved = dict(D.BACKEND)
+    try:
+        D.enable_hip_kernels(["all"])
+        dec = Phi3Decoder(sd, cfg, torch.bfloat16, "cuda")
+        T = sum(lens)
+        x = torch.zeros(((T + 255) // 256 * 256, cfg.hidden), dtype=torch.bfloat16, device="cuda")
+        x[:T] = torch.cat(rows).cuda()
+        tok_f, logits_f = dec.generate_packed(x, lens, max_new_tokens=steps, forced=forced, return_logits=True)
+        tok_free = dec.generate_packed(x, lens, max_new_tokens=steps)
+        end = ref_tok[1][2]                                                    # a token sequence 1 emits at step 2
+        tok_end = dec.generate_packed(x, lens, max_new_tokens=steps, end_id=end, forced=forced)
+    finally:
+        D.BACKEND.update(saved)
+    assert tok_f == ref_tok
+    got, ref = logits_f.cpu().numpy(), ref_logits.numpy()
+    for i in range(steps):
+        r = np.linalg.norm(got[i] - ref[i]) / np.linalg.norm(ref[i])
+        assert r < 3e-2, (i, r)
+    top2 = np.sort(ref, -1)[..., -2:]
+    margin = (top2[..., 1] - top2[..., 0]) / np.linalg.norm(ref, axis=-1) * np.sqrt(ref.shape[-1])   # in units of the per-logit rms
+    for b in range(len(lens)):
+        for i in range(steps):
+            if margin[i, b] > 0.25:
+                assert tok_free[b][i] == ref_tok[b][i], (b, i, margin[i, b])
+            else:
+                break                                                          # after a near-tie the free-running paths may diverge
+    for b in range(len(lens)):                                                 # every sequence is cut at ITS first `end` (inclusive)
+        cut = ref_tok[b].index(end) + 1 if end in ref_tok[b] else steps
+        assert tok_end[b] == ref_tok[b][:cut], (b, tok_end[b], ref_tok[b])
+    assert len(tok_end[1]) == 3
+
+
+def test_policy_forward_generates_text_with_kv_cache():
+    """The reference's per-step call (VLN-POL:329 -> List[str]) end to end on the GPU: packed prefill + KV-cache decode,
+    history update (VLN-POL:466-468), text -> action."""
+    import dataclasses
+    from dynam3d_amd.policy import Dynam3D_VLN, synth_policy_weights
+    from dynam3d_amd.synthetic import INSTRUCTION_64, SyntheticEpisodes
+    cfg = dataclasses.replace(SMALL, clip_dtype=torch.float16, llava_dtype=torch.bfloat16)
+    net = Dynam3D_VLN(cfg, synth_policy_weights(cfg, 0), device="cuda", batch_size=2, max_steps=4)
+    net.feature_fields.initialize_camera_setting(90.0, 90.0)
+    ep = SyntheticEpisodes(2, seed=3, image_hw=224, depth_hw=224)
+    before = [list(h) for h in net.feature_fields.history_actions]
+    for _ in range(2):
+        fr = ep.next()
+        obs = dict(rgb=torch.from_numpy(fr.rgb), depth=torch.from_numpy(fr.depth))
+        texts = net(obs, [INSTRUCTION_64] * 2, [p.tolist() for p in fr.positions], list(fr.headings), patch_segm=fr.patch_segm, max_new_tokens=5)
+        assert len(texts) == 2 and all(isinstance(t, str) for t in texts)
+        acts = net.convert_text_to_action(texts)
+        assert len(acts) == 2
+    after = net.feature_fields.history_actions
+    assert all(len(a) == len(b) for a, b in zip(after, before)) and all(a[-1] == t + "\n" for a, t in zip(after, texts))
