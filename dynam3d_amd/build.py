@@ -24,7 +24,8 @@ HIP_SOURCES = [
     ("attn_kernels.hip", ["-ffp-contract=fast"]),
     ("render_kernels.hip", ["-ffp-contract=off"]),
 ]
-CPP_SOURCES = ["ff_state.cpp", "d3d_error.cpp"]
+CPP_SOURCES = ["ff_state.cpp", "d3d_error.cpp", "phi3_decode.cpp"]
+HOST_CPP_SOURCES = ["ff_state.cpp", "d3d_error.cpp"]      # the CPU-only bookkeeping library (no device entry points)
 
 
 def _newer(src, dst):
@@ -75,7 +76,7 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
 
 
 def build_host_state(force: bool = False) -> str:
-    srcs = [os.path.join(CSRC, s) for s in CPP_SOURCES]
+    srcs = [os.path.join(CSRC, s) for s in HOST_CPP_SOURCES]
     if force or any(_newer(d, HOST_LIB) for s in srcs for d in _deps(s)):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", HOST_LIB] + srcs
         subprocess.check_call(cmd)

@@ -327,7 +327,6 @@ k_decode_attn(const uint16_t* __restrict__ qkv_new /* (B, 3H, HD): this step's r
     __shared__ float qs[HD];
     __shared__ float sc[DEC_MAX_KEYS];
     __shared__ float red[8];
-    __shared__ float part[4][HD];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t rs = (int64_t)3 * H * HD;                                   // fused row stride (elements)
     const int r0 = cu[b], S = cu[b + 1] - r0, L = S + t_new + 1;               // prompt keys + generated (incl. the current one)
@@ -387,33 +386,51 @@ k_decode_attn(const uint16_t* __restrict__ qkv_new /* (B, 3H, HD): this step's r
     if (lane == 0) red[4 + wave] = lsum;
     __syncthreads();
     const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
-    // ---- O = P V: wave w takes keys w, w+4, ...; lane l < HD/2 owns head-dim elements 2l, 2l+1 (one 4-byte load per key)
-    float o0 = 0.f, o1 = 0.f;
-    if (lane < HD / 2) {
-        int j = wave;
-        for (; j + 12 < L; j += 16) {                                          // four keys in flight
-            const uint32_t v0 = *reinterpret_cast<const uint32_t*>(vrow(j) + 2 * lane);
-            const uint32_t v1 = *reinterpret_cast<const uint32_t*>(vrow(j + 4) + 2 * lane);
-            const uint32_t v2 = *reinterpret_cast<const uint32_t*>(vrow(j + 8) + 2 * lane);
-            const uint32_t v3 = *reinterpret_cast<const uint32_t*>(vrow(j + 12) + 2 * lane);
-            const float p0 = sc[j], p1 = sc[j + 4], p2 = sc[j + 8], p3 = sc[j + 12];
-            o0 += (p0 * cvt16<BF16>((uint16_t)v0) + p1 * cvt16<BF16>((uint16_t)v1)) + (p2 * cvt16<BF16>((uint16_t)v2) + p3 * cvt16<BF16>((uint16_t)v3));
-            o1 += (p0 * cvt16<BF16>((uint16_t)(v0 >> 16)) + p1 * cvt16<BF16>((uint16_t)(v1 >> 16))) +
-                  (p2 * cvt16<BF16>((uint16_t)(v2 >> 16)) + p3 * cvt16<BF16>((uint16_t)(v3 >> 16)));
+    // ---- O = P V: thread = (key group g, 16-byte chunk c of the head dim): 256 / (HD/8) key groups stride through the keys,
+    //      eight keys in flight per thread (the loop is bound by load latency, not bandwidth); partial sums meet in LDS
+    constexpr int CH = HD / 8;                          // 12 (hd 96) / 8 (hd 64) chunks per value row
+    constexpr int NG = 256 / CH;                        // 21 / 32 key groups
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int g = tid / CH, c = tid % CH;
+    if (g < NG) {
+        int j = g;
+        for (; j + 7 * NG < L; j += 8 * NG) {
+            uint4 v[8];
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = *reinterpret_cast<const uint4*>(vrow(j + u * NG) + c * 8);
+                p[u] = sc[j + u * NG];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint16_t* e = reinterpret_cast<const uint16_t*>(&v[u]);
+#pragma unroll
+                for (int d = 0; d < 8; ++d) o[d] += p[u] * cvt16<BF16>(e[d]);
+            }
         }
-        for (; j < L; j += 4) {
-            const uint32_t v0 = *reinterpret_cast<const uint32_t*>(vrow(j) + 2 * lane);
-            o0 += sc[j] * cvt16<BF16>((uint16_t)v0);
-            o1 += sc[j] * cvt16<BF16>((uint16_t)(v0 >> 16));
+        for (; j < L; j += NG) {
+            const uint4 v = *reinterpret_cast<const uint4*>(vrow(j) + c * 8);
+            const float p = sc[j];
+            const uint16_t* e = reinterpret_cast<const uint16_t*>(&v);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) o[d] += p * cvt16<BF16>(e[d]);
         }
-        part[wave][2 * lane] = o0;
-        part[wave][2 * lane + 1] = o1;
+    }
+    __syncthreads();                                    // every thread is done with sc[] as probabilities
+    float* acc = sc;                                    // reuse: [NG][HD] partial outputs
+    if (g < NG) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) acc[g * HD + c * 8 + d] = o[d];
     }
     __syncthreads();
     if (tid < HD / 2) {
-        const float a0 = ((part[0][2 * tid] + part[1][2 * tid]) + (part[2][2 * tid] + part[3][2 * tid])) * inv;
-        const float a1 = ((part[0][2 * tid + 1] + part[1][2 * tid + 1]) + (part[2][2 * tid + 1] + part[3][2 * tid + 1])) * inv;
-        *reinterpret_cast<uint32_t*>(out + ((int64_t)b * H + h) * HD + 2 * tid) = pack2<BF16>(a0, a1);
+        float a0 = 0.f, a1 = 0.f;
+        for (int q = 0; q < NG; ++q) {                  // fixed order: deterministic
+            a0 += acc[q * HD + 2 * tid];
+            a1 += acc[q * HD + 2 * tid + 1];
+        }
+        *reinterpret_cast<uint32_t*>(out + ((int64_t)b * H + h) * HD + 2 * tid) = pack2<BF16>(a0 * inv, a1 * inv);
     }
 }
 

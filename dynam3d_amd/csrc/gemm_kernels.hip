@@ -647,6 +647,144 @@ int32_t launch(const void* A, const void* W, void* C, const void* bias, const vo
                        : launch_stages<BF16, EPI, 2>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s);
 }
 
+// ================================================================================================
+// Skinny GEMM for M <= 16 rows (KV-cache decode: 8 sequences x one token): pure weight streaming, bounded by HBM.
+//
+// One WAVE owns 32 output columns over a K slice: per 32-deep step it loads two 16x32 W fragments straight from global memory
+// in MFMA operand layout (16 bytes per lane; no LDS -- a weight element is used once) plus the matching 16x32 x fragment (tiny,
+// cache resident), and issues two MFMAs.  K is cut into `splits` slices so that every SIMD holds several waves with several
+// loads in flight; the slices of a column tile meet through fp32 partials (system-scope stores) and an arrival counter, the last
+// one to arrive sums them in slice order (deterministic) and runs the epilogue.  SwiGLU uses the per-16 interleaved gate/up rows:
+// the wave's two fragments ARE a gate tile and its up tile.
+// ================================================================================================
+constexpr int SK_THREADS = 256;            // 4 waves, each its own (column tile, slice)
+
+template <bool BF16, int EPI>
+__global__ void __launch_bounds__(SK_THREADS)
+k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
+              const uint16_t* __restrict__ residual, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldc, int splits, float* __restrict__ ws,
+              uint32_t* __restrict__ counters) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fi = lane & 15, fg = lane >> 4;
+    const int ntiles = N / 32;
+    const int gw = blockIdx.x * 4 + wave;                      // wave-uniform (SGPR): tile, slice and workspace addresses below
+    if (gw >= ntiles * splits) return;
+    const int ct = gw % ntiles, sl = gw / ntiles;             // slice-major: concurrently running waves stream neighbouring W rows
+    const int nsteps = K / 32;
+    const int s0 = (int)((int64_t)sl * nsteps / splits), s1 = (int)((int64_t)(sl + 1) * nsteps / splits);
+    const uint16_t* w0 = W + (int64_t)(ct * 32 + fi) * ldw + fg * 8;
+    const uint16_t* w1 = w0 + 16 * ldw;
+    const uint16_t* xr = X + (int64_t)(fi < M ? fi : M - 1) * ldx + fg * 8;      // rows >= M: a duplicate, never stored
+    float4v acc0 = float4v{0.f, 0.f, 0.f, 0.f}, acc1 = float4v{0.f, 0.f, 0.f, 0.f};
+    int st = s0;
+    for (; st + 4 <= s1; st += 4) {                            // 12 independent 16-byte loads in flight per lane
+        uint4 a[4], b[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const uint4*>(w0 + (st + u) * 32);
+            b[u] = *reinterpret_cast<const uint4*>(w1 + (st + u) * 32);
+            x[u] = *reinterpret_cast<const uint4*>(xr + (st + u) * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc0 = mfma16<BF16>(a[u], x[u], acc0);
+            acc1 = mfma16<BF16>(b[u], x[u], acc1);
+        }
+    }
+    for (; st < s1; ++st) {
+        const uint4 a = *reinterpret_cast<const uint4*>(w0 + st * 32);
+        const uint4 b = *reinterpret_cast<const uint4*>(w1 + st * 32);
+        const uint4 x = *reinterpret_cast<const uint4*>(xr + st * 32);
+        acc0 = mfma16<BF16>(a, x, acc0);
+        acc1 = mfma16<BF16>(b, x, acc1);
+    }
+    if (splits > 1) {
+        // partials: [tile][slice][2][64 lanes] float4; system-scope accesses (other XCDs' L2s), no fences
+        auto uniform_ptr = [](const char* p) -> const char* {      // (the asm's "s" operand needs a provably wave-uniform address)
+            const uint64_t v = (uint64_t)p;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+            return (const char*)(((uint64_t)hi << 32) | lo);
+        };
+        const char* base = uniform_ptr(reinterpret_cast<const char*>(ws) + ((int64_t)ct * splits) * 2048);
+        const uint32_t vo = (uint32_t)lane * 16u;
+        {
+            const char* mine = uniform_ptr(base + (int64_t)sl * 2048);
+            asm volatile("global_store_dwordx4 %0, %1, %3 sc0 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:1024 sc0 sc1" ::"v"(vo), "v"(acc0), "v"(acc1), "s"(mine) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(counters + ct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived != (uint32_t)(splits - 1)) return;        // not the last slice of this column tile
+        if (lane == 0) __hip_atomic_store(counters + ct, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        acc0 = float4v{0.f, 0.f, 0.f, 0.f};
+        acc1 = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < splits; ++q) {
+            float4v p0, p1;
+            const char* src = uniform_ptr(base + (int64_t)q * 2048);
+            asm volatile("global_load_dwordx4 %0, %2, %3 sc0 sc1\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(p0), "=&v"(p1)
+                         : "v"(vo), "s"(src)
+                         : "memory");
+            acc0 += p0;
+            acc1 += p1;
+        }
+    }
+    if (fi >= M) return;
+    if constexpr (EPI == EPI_SWIGLU) {
+        store4<BF16, EPI>(acc0, acc1, C, bias, residual, fi, ct * 32, fg, ldc);
+    } else {
+        store4<BF16, EPI>(acc0, acc0, C, bias, residual, fi, ct * 32, fg, ldc);
+        store4<BF16, EPI>(acc1, acc1, C, bias, residual, fi, ct * 32 + 16, fg, ldc);
+    }
+}
+
+struct SkinnyWorkspace {
+    float* ws = nullptr;
+    uint32_t* counters = nullptr;
+    size_t bytes = 0;
+    int tiles = 0;
+};
+
+int32_t skinny_workspace(hipStream_t s, size_t bytes, int tiles, SkinnyWorkspace** out) {
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, SkinnyWorkspace> table;
+    std::lock_guard<std::mutex> lock(mu);
+    SkinnyWorkspace& w = table[s];
+    if (w.bytes < bytes || w.tiles < tiles) {
+        if (w.ws) (void)hipFree(w.ws);
+        if (w.counters) (void)hipFree(w.counters);
+        w = SkinnyWorkspace{};
+        const size_t nb = bytes > (8u << 20) ? bytes : (8u << 20);
+        const int nt = tiles > 4096 ? tiles : 4096;
+        D3D_HIP(hipMalloc(&w.ws, nb));
+        D3D_HIP(hipMalloc(&w.counters, (size_t)nt * sizeof(uint32_t)));
+        D3D_HIP(hipMemset(w.counters, 0, (size_t)nt * sizeof(uint32_t)));
+        w.bytes = nb;
+        w.tiles = nt;
+    }
+    *out = &w;
+    return D3D_OK;
+}
+
+template <bool BF16, int EPI>
+int32_t launch_skinny(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
+                      int64_t ldw, int64_t ldc, hipStream_t s) {
+    const int ntiles = N / 32, nsteps = K / 32;
+    // enough waves for ~4 per SIMD, at least 8 K steps per slice
+    int splits = (4 * 4 * cu_count() + ntiles - 1) / ntiles;
+    if (splits > nsteps / 8) splits = nsteps / 8;
+    if (splits < 1) splits = 1;
+    if (splits > 16) splits = 16;
+    SkinnyWorkspace* w = nullptr;
+    int32_t rc = skinny_workspace(s, (size_t)ntiles * splits * 2048, ntiles, &w);
+    if (rc != D3D_OK) return rc;
+    const int waves = ntiles * splits;
+    hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI>), dim3((waves + 3) / 4), dim3(SK_THREADS), 0, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
+                       (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, splits, w->ws, w->counters);
+    D3D_LAUNCH_CHECK();
+}
+
 }  // namespace
 
 extern "C" {
@@ -664,6 +802,8 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
     // Between one and three rounds the partial last round decides: it is K-split when it can be cut at least three ways
     // (o_proj / down_proj at M = 6400: 300 tiles = one round + 44 tiles x 5 slices; measured 0.120 / 0.277 ms against
     // 0.132 / 0.306 ms for the 128x128 kernel and 0.148 / 0.330 ms unsplit); otherwise the finer 128x128 grid wins.
+    if (M <= 16 && N % 32 == 0 && K % 32 == 0 && (epilogue == EPI_NONE || epilogue == EPI_RES || epilogue == EPI_SWIGLU || epilogue == EPI_BIAS))
+        return d3d_gemm_nt_tile(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, dtype, epilogue, 16, stream);   // weight streaming
     const int64_t rows256 = (int64_t)(M / TM) * TM;
     const int64_t blocks256 = (rows256 / TM) * (N / TN);
     int tile = 128;
@@ -688,6 +828,26 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
 int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream) {
     if (M <= 0) return D3D_OK;
+    if (tile == 16) {
+        if (M > 16 || N % 32 != 0 || K % 32 != 0 || (lda & 7) || (ldw & 7) || (ldc & 3)) {
+            d3d_set_error_("d3d_gemm_nt_tile: the skinny kernel needs M <= 16, N % 32 == 0, K % 32 == 0, lda/ldw % 8 == 0, ldc % 4 == 0");
+            return D3D_EINVAL;
+        }
+        hipStream_t s16 = (hipStream_t)stream;
+#define D3D_SKINNY_CASE(E)                                                                                            \
+    case E:                                                                                                           \
+        return dtype == 0 ? launch_skinny<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s16)               \
+                          : launch_skinny<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s16);
+        switch (epilogue) {
+            D3D_SKINNY_CASE(EPI_NONE)
+            D3D_SKINNY_CASE(EPI_BIAS)
+            D3D_SKINNY_CASE(EPI_RES)
+            D3D_SKINNY_CASE(EPI_SWIGLU)
+        }
+#undef D3D_SKINNY_CASE
+        d3d_set_error_("d3d_gemm_nt_tile: the skinny kernel supports epilogues none, bias, residual, SwiGLU");
+        return D3D_EINVAL;
+    }
     if (tile != 128 && tile != 130 && tile != 132 && tile != 256 && tile != 257 && tile != 258) {
         d3d_set_error_("d3d_gemm_nt_tile: tile must be 128 (130 / 132: 2 / 4 LDS stages forced), 256 (K-half steps), 257 (whole-K-tile steps) or 258 (257 + split-K tail)");
         return D3D_EINVAL;

@@ -20,6 +20,7 @@ _lib.register("d3d_flash_attention", [vp, vp, vp, i32, i32, i32, i32, i64, i64, 
 _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
 _lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
 _lib.register("d3d_decode_attention", [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])
+_lib.register("d3d_phi3_decode_token", [vp])
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -32,6 +33,24 @@ def interleave_gate_up(w: torch.Tensor, block: int = 16) -> torch.Tensor:
     I = w.shape[0] // 2
     g, u = w[:I].view(I // block, block, -1), w[I:].view(I // block, block, -1)
     return torch.stack([g, u], dim=1).reshape(2 * I, -1).contiguous()
+
+
+class Phi3DecodeArgs(C.Structure):
+    """ctypes mirror of `d3d_phi3_decode_args` (include/dynam3d_hip.h)."""
+    _fields_ = [("n_layers", C.c_int32), ("rows", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
+                ("mlp", C.c_int32), ("vocab", C.c_int32), ("dtype", C.c_int32), ("rms_eps", C.c_float),
+                ("x", C.c_void_p), ("h", C.c_void_p), ("qkv", C.c_void_p), ("attn", C.c_void_p), ("act", C.c_void_p), ("logits", C.c_void_p),
+                ("qkv_w", C.POINTER(C.c_void_p)), ("o_w", C.POINTER(C.c_void_p)), ("gate_up_w", C.POINTER(C.c_void_p)),
+                ("down_w", C.POINTER(C.c_void_p)), ("n1", C.POINTER(C.c_void_p)), ("n2", C.POINTER(C.c_void_p)),
+                ("norm_w", C.c_void_p), ("lm_head_w", C.c_void_p), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p), ("pos", C.c_void_p),
+                ("prompt_qkv", C.POINTER(C.c_void_p)), ("cu_seqlens", C.c_void_p), ("knew", C.c_void_p), ("vnew", C.c_void_p),
+                ("cache_layer_stride_bytes", C.c_int64), ("t_new", C.c_int32), ("t_max", C.c_int32), ("max_prompt_len", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (kept alive by the caller together with the tensors)."""
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
 class HipDense:
@@ -50,7 +69,9 @@ class HipDense:
     @staticmethod
     def gemm_ok(x, w):
         K = x.shape[-1]
-        return (w.shape[0] % 128 == 0 and K % 64 == 0 and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16)
+        rows = x.numel() // max(K, 1)
+        shape_ok = (w.shape[0] % 128 == 0 and K % 64 == 0) or (rows <= 16 and w.shape[0] % 32 == 0 and K % 32 == 0)   # skinny kernel
+        return (shape_ok and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16)
                 and x.stride(-1) == 1 and w.is_contiguous())
 
     TILE = 0   # 0 = library heuristic, 128 / 130 / 132 / 256 / 257 / 258 = force a kernel variant (benchmarking, tests)
@@ -125,6 +146,11 @@ class HipDense:
         _lib.check(self.lib.d3d_decode_attention(_p(qkv_new), _p(prompt_qkv), _p(cu_seqlens), _p(knew), _p(vnew), _p(out), B, n_heads, hd, t_new, Tmax,
                                                  max_prompt_len, 0 if qkv_new.dtype == torch.bfloat16 else 1, self._stream()))
         return out
+
+    def phi3_decode_token(self, args: "Phi3DecodeArgs"):
+        """All launches of one KV-cache decode token, issued from C++ (d3d_phi3_decode_token)."""
+        args.stream = self._stream()
+        _lib.check(self.lib.d3d_phi3_decode_token(C.byref(args)))
 
     def resize_normalize(self, rgb_u8, size, mean, std):
         import numpy as np

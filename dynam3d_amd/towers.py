@@ -334,6 +334,7 @@ class Phi3Decoder:
         cos, sin = self._rope(max(lens) + max_new_tokens + 1)
         lens_d = torch.tensor(lens, dtype=torch.int32, device=self.device)
         gen, done, all_logits = [[] for _ in range(B)], [False] * B, []
+        run = None
         for i in range(max_new_tokens):
             if return_logits:
                 all_logits.append(logits)
@@ -345,19 +346,47 @@ class Phi3Decoder:
                     done[b] = end_id is not None and int(nxt_h[b]) == end_id
             if i == max_new_tokens - 1 or all(done):
                 break
-            xt = self.embed_tokens(nxt.long()).to(self.dtype)                     # (B, hidden): generated token i at position lens + i
-            pos = lens_d + i
-            for li, L in enumerate(self.layers):
-                h = D.rms_norm(xt, L["n1"], c.rms_eps)
-                qkv = D.linear(h, L["qkv_w"], None)
-                D.rope_packed_(qkv, c.heads + c.kv_heads, hd, cos, sin, pos)
-                a = D.decode_attention(qkv, kv[li], cu, side[li, 0], side[li, 1], H, i, max(lens))
-                xt = D.linear(a, L["o_w"], None, residual=xt)
-                h = D.rms_norm(xt, L["n2"], c.rms_eps)
-                act = D.linear_swiglu(h, L["gu_w"], self.interleave_gu)
-                xt = D.linear(act, L["down_w"], None, residual=xt)
-            logits = D.linear(D.rms_norm(xt, self.norm_w, c.rms_eps), self.lm_head_w, None).float()
+            xt = self.embed_tokens(nxt.long()).to(self.dtype).contiguous()        # (B, hidden): generated token i at position lens + i
+            pos = (lens_d + i).contiguous()
+            if run is None:
+                run = self._decode_runner(B, kv, cu, side, cos, sin, max(lens))
+            logits = run(xt, pos, i)
         return (gen, torch.stack(all_logits)) if return_logits else gen
+
+    def _decode_runner(self, B, kv, cu, side, cos, sin, max_prompt_len):
+        """One decode token = one C call (d3d_phi3_decode_token issues the ~260 launches from C++; from Python they cost more
+        host time than the 8-row kernels run).  Returns run(x, pos, t_new) -> logits (B, vocab) float32."""
+        from .hip_dense import HipDense, Phi3DecodeArgs, ptr_array
+        c = self.cfg
+        if not (self.interleave_gu and B <= 16):
+            raise RuntimeError("KV-cache decode needs the HIP GEMM backend (interleaved gate/up weights) and <= 16 sequences")
+        hdn = HipDense()
+        dev, dt = self.device, self.dtype
+        buf = dict(h=torch.empty((B, c.hidden), dtype=dt, device=dev), qkv=torch.empty((B, 3 * c.hidden), dtype=dt, device=dev),
+                   attn=torch.empty((B, c.hidden), dtype=dt, device=dev), act=torch.empty((B, c.mlp), dtype=dt, device=dev),
+                   logits=torch.empty((B, c.vocab), dtype=dt, device=dev))
+        if getattr(self, "_w_arrays", None) is None:                            # weight pointer tables: built once per decoder
+            self._w_arrays = {k: ptr_array([L[k] for L in self.layers]) for k in ("qkv_w", "o_w", "gu_w", "down_w", "n1", "n2")}
+        wa = self._w_arrays
+        kv_arr = ptr_array(kv)
+        a = Phi3DecodeArgs()
+        a.n_layers, a.rows, a.hidden, a.heads, a.head_dim, a.mlp, a.vocab = c.layers, B, c.hidden, c.heads, c.head_dim, c.mlp, c.vocab
+        a.dtype, a.rms_eps = (0 if dt == torch.bfloat16 else 1), c.rms_eps
+        a.h, a.qkv, a.attn, a.act, a.logits = (buf[k].data_ptr() for k in ("h", "qkv", "attn", "act", "logits"))
+        a.qkv_w, a.o_w, a.gate_up_w, a.down_w, a.n1, a.n2 = wa["qkv_w"], wa["o_w"], wa["gu_w"], wa["down_w"], wa["n1"], wa["n2"]
+        a.norm_w, a.lm_head_w = self.norm_w.data_ptr(), self.lm_head_w.data_ptr()
+        a.cos_t, a.sin_t = cos.data_ptr(), sin.data_ptr()
+        a.prompt_qkv, a.cu_seqlens = kv_arr, cu.data_ptr()
+        a.knew, a.vnew = side[0, 0].data_ptr(), side[0, 1].data_ptr()
+        a.cache_layer_stride_bytes = side.stride(0) * side.element_size()
+        a.t_max, a.max_prompt_len = side.shape[3], max_prompt_len
+        keep = (buf, kv_arr, kv, side, cos, sin, cu)                           # referenced by raw pointers above
+
+        def run(x, pos, t_new):
+            a.x, a.pos, a.t_new = x.data_ptr(), pos.data_ptr(), t_new
+            hdn.phi3_decode_token(a)
+            return buf["logits"].float() if keep else None
+        return run
 
     @torch.no_grad()
     def prefill_logits(self, inputs_embeds: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:

@@ -163,7 +163,8 @@ int32_t d3d_agent_frame_compact(const float* pool_pos_d, const float* pool_fts_d
  * ---------------------------------------------------------------------------------------------- */
 /* C = epilogue(A[M,K] W[N,K]^T): nn.Linear layout.  epilogue: 0 none, 1 +bias, 2 +bias QuickGELU (clip/model.py:162),
  * 3 +bias GELU, 4 +residual, 5 +bias +residual, 6 SwiGLU over per-16 interleaved gate/up rows of W (writes N/2 cols).
- * Needs N % 128 == 0, K % 64 == 0, lda/ldw % 8 == 0. */
+ * Needs N % 128 == 0, K % 64 == 0, lda/ldw % 8 == 0.  M <= 16 (KV-cache decode rows) with epilogue 0/1/4/6 streams the weights
+ * once through a no-LDS kernel (N % 32 == 0, K % 32 == 0 suffice there). */
 int32_t d3d_gemm_nt(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
                     int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
                     void* stream);
@@ -175,6 +176,35 @@ int32_t d3d_gemm_nt(const void* A_d, const void* W_d, void* C_d, const void* bia
 int32_t d3d_gemm_nt_tile(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
                          int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
                          int32_t tile, void* stream);
+/* One KV-cache decode token through the whole Phi-3 stack (HF Phi3DecoderLayer x n_layers + final norm + lm_head under
+ * `llava.generate`, VLN-POL:463), every launch issued from C++.  All pointers are device pointers except the per-layer pointer
+ * ARRAYS, which are host arrays of device pointers.  gate_up weights in the per-16 interleaved row order of epilogue 6;
+ * rows <= 16; x is updated in place; logits (rows, vocab) in the activations' dtype. */
+typedef struct d3d_phi3_decode_args {
+    int32_t n_layers, rows, hidden, heads, head_dim, mlp, vocab, dtype;
+    float rms_eps;
+    void* x;                          /* (rows, hidden) residual stream: embedding of the token to process -> final hidden state */
+    void *h, *qkv, *attn, *act;       /* scratch: (rows, hidden), (rows, 3*hidden), (rows, hidden), (rows, mlp) */
+    void* logits;                     /* (rows, vocab) */
+    const void* const* qkv_w;         /* [n_layers] (3*hidden, hidden) */
+    const void* const* o_w;           /* [n_layers] (hidden, hidden) */
+    const void* const* gate_up_w;     /* [n_layers] (2*mlp, hidden), interleaved */
+    const void* const* down_w;        /* [n_layers] (hidden, mlp) */
+    const float* const* n1;           /* [n_layers] input_layernorm weight (float32) */
+    const float* const* n2;           /* [n_layers] post_attention_layernorm weight */
+    const float* norm_w;              /* final norm */
+    const void* lm_head_w;            /* (vocab, hidden) */
+    const float *cos_t, *sin_t;       /* RoPE tables (positions, head_dim/2) */
+    const int32_t* pos;               /* (rows) position of this token in its sequence */
+    const void* const* prompt_qkv;    /* [n_layers] the layer's prefill QKV buffer (packed rows, post-RoPE) */
+    const int32_t* cu_seqlens;        /* (rows + 1) */
+    void *knew, *vnew;                /* layer 0's (rows, t_max, heads, head_dim) side caches; layer l at + l * cache_layer_stride_bytes */
+    int64_t cache_layer_stride_bytes;
+    int32_t t_new, t_max, max_prompt_len;
+    void* stream;
+} d3d_phi3_decode_args;
+int32_t d3d_phi3_decode_token(const d3d_phi3_decode_args* args);
+
 /* One decode step of causal self-attention with a KV cache -- the `use_cache` branch of the HF Phi-3 attention under
  * `llava.generate(max_new_tokens=20, do_sample=False)` (VLN-POL:463).  qkv_new (B, 3H, hd): this step's fused projection after
  * RoPE; prompt_qkv: the layer's prefill buffer (packed rows, post-RoPE) with cu_seqlens (B+1); knew / vnew (B, Tmax, H, hd): the

@@ -101,6 +101,30 @@ def test_gemm_split_k_tail(hd, dt, tol):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
+def test_gemm_skinny_decode_rows(hd, dt, tol):
+    """M <= 16 rows (KV-cache decode) take the weight-streaming kernel: one wave per 32 output columns and K slice, slices reduced
+    in slice order by the last arriver.  1 / 8 / 16 rows, the Phi-3 decode shapes (scaled), a vocabulary-sized N, K not a
+    multiple of the slice count, all supported epilogues; repeated launches reuse the arrival counters; bit-identical reruns."""
+    from dynam3d_amd.hip_dense import interleave_gate_up
+    torch.manual_seed(4)
+    for M, N, K in ((8, 9216, 3072), (8, 3072, 8192), (1, 3072, 3072), (16, 16384, 1024), (8, 32064, 768), (5, 96, 416)):
+        x = (torch.randn(M, K, device="cuda") * 0.7).to(dt)
+        w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
+        w[3] *= 4.0
+        x[:, 5] += 1.0
+        b = (torch.randn(N, device="cuda") * 0.3).to(dt)
+        r = torch.randn(M, N, device="cuda").to(dt)
+        y32 = x.float() @ w.float().t()
+        for rep in range(2):
+            assert rel(hd.linear(x, w, None, None).float(), y32) < tol, (M, N, K, "none")
+            assert rel(hd.linear(x, w, b, None).float(), y32 + b.float()) < tol, (M, N, K, "bias")
+            assert rel(hd.linear(x, w, None, None, r).float(), y32 + r.float()) < tol, (M, N, K, "res")
+            if N % 32 == 0 and (N // 2) % 16 == 0:
+                assert rel(hd.linear_swiglu(x, interleave_gate_up(w)).float(), y32[:, N // 2:] * F.silu(y32[:, :N // 2])) < tol, (M, N, K, "swiglu")
+        assert torch.equal(hd.linear(x, w, None, None, r), hd.linear(x, w, None, None, r))
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
 def test_norms_rope_swiglu(hd, dt, tol):
     torch.manual_seed(2)
     for D in (768, 1024, 3072, 4096, 128):
