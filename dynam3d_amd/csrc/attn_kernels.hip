@@ -323,29 +323,53 @@ template <bool BF16, int HD>
 __global__ void __launch_bounds__(256)
 k_decode_attn(const uint16_t* __restrict__ qkv_new /* (B, 3H, HD): this step's rotated q,k and v */, const uint16_t* __restrict__ prompt /* (T, 3H, HD) */,
               const int32_t* __restrict__ cu, uint16_t* __restrict__ knew, uint16_t* __restrict__ vnew /* (B, Tmax, H, HD) */,
-              uint16_t* __restrict__ out /* (B, H, HD) */, int H, int t_new, int Tmax, float scale) {
+              uint16_t* __restrict__ out /* (B, H, HD) */, int H, int t_new, int Tmax, float scale, const float* __restrict__ cos_t,
+              const float* __restrict__ sin_t, const int32_t* __restrict__ pos /* RoPE fused: qkv_new is then UN-rotated */) {
     __shared__ float qs[HD];
+    __shared__ __attribute__((aligned(16))) uint16_t kcur[HD];
     __shared__ float sc[DEC_MAX_KEYS];
     __shared__ float red[8];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t rs = (int64_t)3 * H * HD;                                   // fused row stride (elements)
     const int r0 = cu[b], S = cu[b + 1] - r0, L = S + t_new + 1;               // prompt keys + generated (incl. the current one)
     const uint16_t* qrow = qkv_new + (int64_t)b * rs + (int64_t)h * HD;
-    // append the current token's k / v to the side cache (first HD*2/8 threads copy 16 bytes each)
-    if (tid < 2 * HD / 8) {
-        const int which = tid / (HD / 8), c = tid % (HD / 8);
-        const uint4 v = *reinterpret_cast<const uint4*>(qrow + (int64_t)(which + 1) * H * HD + c * 8);
-        uint16_t* dst = (which == 0 ? knew : vnew) + (((int64_t)b * Tmax + t_new) * H + h) * HD + c * 8;
-        *reinterpret_cast<uint4*>(dst) = v;
+    // this token's q and k: rotated here (half-split RoPE at position pos[b], same arithmetic as k_rope, results rounded to 16 bit
+    // like the prefill's in-place rotation) or taken as they are; k goes to LDS (it is key L-1) and to the side cache, v to the cache
+    constexpr int HALF = HD / 2;
+    if (tid < HALF) {
+        float q1 = cvt16<BF16>(qrow[tid]), q2 = cvt16<BF16>(qrow[tid + HALF]);
+        float k1 = cvt16<BF16>(qrow[(int64_t)H * HD + tid]), k2 = cvt16<BF16>(qrow[(int64_t)H * HD + tid + HALF]);
+        uint16_t kr1, kr2;
+        if (cos_t) {
+            const float c = cos_t[(int64_t)pos[b] * HALF + tid], sn = sin_t[(int64_t)pos[b] * HALF + tid];
+            const uint32_t qp = pack2<BF16>(q1 * c - q2 * sn, q2 * c + q1 * sn);
+            const uint32_t kp2 = pack2<BF16>(k1 * c - k2 * sn, k2 * c + k1 * sn);
+            q1 = cvt16<BF16>((uint16_t)qp);
+            q2 = cvt16<BF16>((uint16_t)(qp >> 16));
+            kr1 = (uint16_t)kp2;
+            kr2 = (uint16_t)(kp2 >> 16);
+        } else {
+            kr1 = qrow[(int64_t)H * HD + tid];
+            kr2 = qrow[(int64_t)H * HD + tid + HALF];
+        }
+        qs[tid] = q1 * scale;
+        qs[tid + HALF] = q2 * scale;
+        kcur[tid] = kr1;
+        kcur[tid + HALF] = kr2;
+        uint16_t* kd = knew + (((int64_t)b * Tmax + t_new) * H + h) * HD;
+        kd[tid] = kr1;
+        kd[tid + HALF] = kr2;
+    } else if (tid >= 64 && tid < 64 + HD / 8) {
+        const int c = tid - 64;
+        const uint4 v = *reinterpret_cast<const uint4*>(qrow + (int64_t)2 * H * HD + c * 8);
+        *reinterpret_cast<uint4*>(vnew + (((int64_t)b * Tmax + t_new) * H + h) * HD + c * 8) = v;
     }
-    if (tid < HD) qs[tid] = cvt16<BF16>(qrow[tid]) * scale;
     __syncthreads();
     // key j: prompt row | earlier generated token (side cache, written by EARLIER launches) | the current token, read from
     // qkv_new itself so that nothing written by this launch is read back by it
     auto krow = [&](int j) -> const uint16_t* {
         if (j < S) return prompt + (int64_t)(r0 + j) * rs + (int64_t)(H + h) * HD;
-        if (j == L - 1) return qrow + (int64_t)H * HD;
-        return knew + (((int64_t)b * Tmax + (j - S)) * H + h) * HD;
+        return knew + (((int64_t)b * Tmax + (j - S)) * H + h) * HD;                 // (j == L-1 is served from LDS below)
     };
     auto vrow = [&](int j) -> const uint16_t* {
         if (j < S) return prompt + (int64_t)(r0 + j) * rs + (int64_t)(2 * H + h) * HD;
@@ -356,10 +380,11 @@ k_decode_attn(const uint16_t* __restrict__ qkv_new /* (B, 3H, HD): this step's r
     float tmax = -INFINITY;
     for (int j = tid; j < L; j += 256) {
         const uint16_t* kp = krow(j);
+        const bool cur = j == L - 1;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int c = 0; c < HD / 8; ++c) {
-            const uint4 kv = *reinterpret_cast<const uint4*>(kp + c * 8);
+            const uint4 kv = cur ? *reinterpret_cast<const uint4*>(kcur + c * 8) : *reinterpret_cast<const uint4*>(kp + c * 8);
             const uint16_t* e = reinterpret_cast<const uint16_t*>(&kv);
             s0 += qs[c * 8 + 0] * cvt16<BF16>(e[0]) + qs[c * 8 + 4] * cvt16<BF16>(e[4]);
             s1 += qs[c * 8 + 1] * cvt16<BF16>(e[1]) + qs[c * 8 + 5] * cvt16<BF16>(e[5]);
@@ -475,11 +500,12 @@ int32_t d3d_flash_attention(const void* qkv, void* out, void* vt_scratch, int32_
     D3D_LAUNCH_CHECK();
 }
 
-// One decode step of causal self-attention with a KV cache (see k_decode_attn).  qkv_new: (B, 3H, hd) this step's fused projection
-// AFTER RoPE; prompt_qkv: the layer's prefill buffer (packed rows, post-RoPE) with cu_seqlens (B+1); knew / vnew: (B, Tmax, H, hd)
+// One decode step of causal self-attention with a KV cache (see k_decode_attn).  qkv_new: (B, 3H, hd) this step's fused projection,
+// BEFORE RoPE when cos_t / sin_t / pos are given (the kernel rotates q and k itself), after RoPE when they are null; prompt_qkv: the layer's prefill buffer (packed rows, post-RoPE) with cu_seqlens (B+1); knew / vnew: (B, Tmax, H, hd)
 // side caches, filled for tokens < t_new by earlier calls -- this call appends token t_new.  out: (B, H, hd).
 int32_t d3d_decode_attention(const void* qkv_new, const void* prompt_qkv, const int32_t* cu_seqlens, void* knew, void* vnew, void* out, int32_t B,
-                             int32_t H, int32_t head_dim, int32_t t_new, int32_t Tmax, int32_t max_prompt_len, int32_t dtype, void* stream) {
+                             int32_t H, int32_t head_dim, int32_t t_new, int32_t Tmax, int32_t max_prompt_len, const float* cos_t, const float* sin_t,
+                             const int32_t* pos, int32_t dtype, void* stream) {
     if (B <= 0) return D3D_OK;
     if ((head_dim != 64 && head_dim != 96) || t_new < 0 || t_new >= Tmax || max_prompt_len + Tmax > DEC_MAX_KEYS) {
         d3d_set_error_("d3d_decode_attention: head_dim must be 64 or 96, 0 <= t_new < Tmax, prompt + Tmax <= 4160 keys");
@@ -489,7 +515,7 @@ int32_t d3d_decode_attention(const void* qkv_new, const void* prompt_qkv, const 
     dim3 grid(H, B), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define D3D_DEC(BF, HDV) hipLaunchKernelGGL((k_decode_attn<BF, HDV>), grid, block, 0, s, (const uint16_t*)qkv_new, (const uint16_t*)prompt_qkv, cu_seqlens, \
-                                            (uint16_t*)knew, (uint16_t*)vnew, (uint16_t*)out, H, t_new, Tmax, scale)
+                                            (uint16_t*)knew, (uint16_t*)vnew, (uint16_t*)out, H, t_new, Tmax, scale, cos_t, sin_t, pos)
     if (dtype == 0) { if (head_dim == 96) D3D_DEC(true, 96); else D3D_DEC(true, 64); }
     else { if (head_dim == 96) D3D_DEC(false, 96); else D3D_DEC(false, 64); }
 #undef D3D_DEC

@@ -650,31 +650,67 @@ int32_t launch(const void* A, const void* W, void* C, const void* bias, const vo
 // ================================================================================================
 // Skinny GEMM for M <= 16 rows (KV-cache decode: 8 sequences x one token): pure weight streaming, bounded by HBM.
 //
-// One WAVE owns 32 output columns over a K slice: per 32-deep step it loads two 16x32 W fragments straight from global memory
-// in MFMA operand layout (16 bytes per lane; no LDS -- a weight element is used once) plus the matching 16x32 x fragment (tiny,
-// cache resident), and issues two MFMAs.  K is cut into `splits` slices so that every SIMD holds several waves with several
-// loads in flight; the slices of a column tile meet through fp32 partials (system-scope stores) and an arrival counter, the last
-// one to arrive sums them in slice order (deterministic) and runs the epilogue.  SwiGLU uses the per-16 interleaved gate/up rows:
-// the wave's two fragments ARE a gate tile and its up tile.
+// One WORKGROUP owns 32 output columns; its 4 / 8 / 16 waves split K.  Per 32-deep step a wave loads two 16x32 W fragments
+// straight from global memory in MFMA operand layout (16 bytes per lane; no LDS staging -- a weight element is used once) plus
+// the matching 16x32 x fragment (tiny, cache resident) and issues two MFMAs; the waves' accumulators meet in LDS and wave 0
+// sums them in wave order (deterministic) and runs the epilogue.  (A first version cut K across workgroups with fp32 partials
+// in global memory and an arrival counter: 6 us of fix-up on a 12 us o_proj.)  SwiGLU uses the per-16 interleaved gate/up
+// rows: the two fragments ARE a gate tile and its up tile.
+// NORM: the RMSNorm in front of the projection is applied to the x fragments on the fly -- rstd per row by one wave per row with
+// exactly k_norm's summation order, then bf16((x * rstd) * g) element by element, so the result is bit-identical to running
+// d3d_norm first -- which removes two launches of ~9 us per layer from the decode token.
 // ================================================================================================
-constexpr int SK_THREADS = 256;            // 4 waves, each its own (column tile, slice)
-
-template <bool BF16, int EPI>
-__global__ void __launch_bounds__(SK_THREADS)
+// HALF: 16 instead of 32 columns per workgroup (twice as many workgroups: the narrow o_proj / down_proj then cover 192 CUs, not 96)
+template <bool BF16, int EPI, bool NORM, bool HALF>
+__global__ void __launch_bounds__(1024)
 k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
-              const uint16_t* __restrict__ residual, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldc, int splits, float* __restrict__ ws,
-              uint32_t* __restrict__ counters) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+              const uint16_t* __restrict__ residual, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldc, const float* __restrict__ norm_w,
+              float eps) {
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];      // [NW][2][64] float4, then rstd[16]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
     const int fi = lane & 15, fg = lane >> 4;
-    const int ntiles = N / 32;
-    const int gw = blockIdx.x * 4 + wave;                      // wave-uniform (SGPR): tile, slice and workspace addresses below
-    if (gw >= ntiles * splits) return;
-    const int ct = gw % ntiles, sl = gw / ntiles;             // slice-major: concurrently running waves stream neighbouring W rows
+    const int ct = blockIdx.x;
     const int nsteps = K / 32;
-    const int s0 = (int)((int64_t)sl * nsteps / splits), s1 = (int)((int64_t)(sl + 1) * nsteps / splits);
-    const uint16_t* w0 = W + (int64_t)(ct * 32 + fi) * ldw + fg * 8;
-    const uint16_t* w1 = w0 + 16 * ldw;
+    const int s0 = (int)((int64_t)wave * nsteps / NW), s1 = (int)((int64_t)(wave + 1) * nsteps / NW);
+    float4v* red = reinterpret_cast<float4v*>(sk_lds);
+    float* rs = sk_lds + NW * 2 * 64 * 4;
+    float my_r = 1.f;
+    if constexpr (NORM) {
+        for (int m = wave; m < M; m += NW) {                   // one wave per row, k_norm's lane mapping and reduction order
+            const uint16_t* xr0 = X + (int64_t)m * ldx;
+            float ss = 0.f;
+            for (int off = lane * 8; off < K; off += 512) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(xr0 + off);
+                const uint16_t* hh = reinterpret_cast<const uint16_t*>(&raw);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float v = to_f32<BF16>(hh[q]);
+                    ss += v * v;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+            if (lane == 0) rs[m] = rsqrtf(ss / (float)K + eps);
+        }
+        __syncthreads();
+        my_r = rs[fi < M ? fi : M - 1];
+    }
+    constexpr int COLS = HALF ? 16 : 32;
+    const uint16_t* w0 = W + (int64_t)(ct * COLS + fi) * ldw + fg * 8;
+    const uint16_t* w1 = HALF ? w0 : w0 + 16 * ldw;
     const uint16_t* xr = X + (int64_t)(fi < M ? fi : M - 1) * ldx + fg * 8;      // rows >= M: a duplicate, never stored
+    const float* gr = norm_w + fg * 8;
+    auto xfrag = [&](int st) -> uint4 {
+        uint4 x = *reinterpret_cast<const uint4*>(xr + st * 32);
+        if constexpr (NORM) {
+            const float4 g0 = *reinterpret_cast<const float4*>(gr + st * 32), g1 = *reinterpret_cast<const float4*>(gr + st * 32 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            uint16_t* e = reinterpret_cast<uint16_t*>(&x);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e[q] = from_f32<BF16>(to_f32<BF16>(e[q]) * my_r * gg[q]);
+        }
+        return x;
+    };
     float4v acc0 = float4v{0.f, 0.f, 0.f, 0.f}, acc1 = float4v{0.f, 0.f, 0.f, 0.f};
     int st = s0;
     for (; st + 4 <= s1; st += 4) {                            // 12 independent 16-byte loads in flight per lane
@@ -682,107 +718,85 @@ k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, ui
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             a[u] = *reinterpret_cast<const uint4*>(w0 + (st + u) * 32);
-            b[u] = *reinterpret_cast<const uint4*>(w1 + (st + u) * 32);
-            x[u] = *reinterpret_cast<const uint4*>(xr + (st + u) * 32);
+            if constexpr (!HALF) b[u] = *reinterpret_cast<const uint4*>(w1 + (st + u) * 32);
+            x[u] = xfrag(st + u);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             acc0 = mfma16<BF16>(a[u], x[u], acc0);
-            acc1 = mfma16<BF16>(b[u], x[u], acc1);
+            if constexpr (!HALF) acc1 = mfma16<BF16>(b[u], x[u], acc1);
         }
     }
     for (; st < s1; ++st) {
         const uint4 a = *reinterpret_cast<const uint4*>(w0 + st * 32);
-        const uint4 b = *reinterpret_cast<const uint4*>(w1 + st * 32);
-        const uint4 x = *reinterpret_cast<const uint4*>(xr + st * 32);
+        const uint4 x = xfrag(st);
         acc0 = mfma16<BF16>(a, x, acc0);
-        acc1 = mfma16<BF16>(b, x, acc1);
-    }
-    if (splits > 1) {
-        // partials: [tile][slice][2][64 lanes] float4; system-scope accesses (other XCDs' L2s), no fences
-        auto uniform_ptr = [](const char* p) -> const char* {      // (the asm's "s" operand needs a provably wave-uniform address)
-            const uint64_t v = (uint64_t)p;
-            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-            return (const char*)(((uint64_t)hi << 32) | lo);
-        };
-        const char* base = uniform_ptr(reinterpret_cast<const char*>(ws) + ((int64_t)ct * splits) * 2048);
-        const uint32_t vo = (uint32_t)lane * 16u;
-        {
-            const char* mine = uniform_ptr(base + (int64_t)sl * 2048);
-            asm volatile("global_store_dwordx4 %0, %1, %3 sc0 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:1024 sc0 sc1" ::"v"(vo), "v"(acc0), "v"(acc1), "s"(mine) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t arrived = 0;
-        if (lane == 0) arrived = __hip_atomic_fetch_add(counters + ct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        arrived = __builtin_amdgcn_readfirstlane(arrived);
-        if (arrived != (uint32_t)(splits - 1)) return;        // not the last slice of this column tile
-        if (lane == 0) __hip_atomic_store(counters + ct, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        acc0 = float4v{0.f, 0.f, 0.f, 0.f};
-        acc1 = float4v{0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < splits; ++q) {
-            float4v p0, p1;
-            const char* src = uniform_ptr(base + (int64_t)q * 2048);
-            asm volatile("global_load_dwordx4 %0, %2, %3 sc0 sc1\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024 sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(p0), "=&v"(p1)
-                         : "v"(vo), "s"(src)
-                         : "memory");
-            acc0 += p0;
-            acc1 += p1;
+        if constexpr (!HALF) {
+            const uint4 b = *reinterpret_cast<const uint4*>(w1 + st * 32);
+            acc1 = mfma16<BF16>(b, x, acc1);
         }
     }
-    if (fi >= M) return;
+    red[(wave * 2 + 0) * 64 + lane] = acc0;
+    red[(wave * 2 + 1) * 64 + lane] = acc1;
+    __syncthreads();
+    if (wave != 0 || fi >= M) return;
+    acc0 = red[lane];
+    acc1 = red[64 + lane];
+    for (int q = 1; q < NW; ++q) {                             // wave order: deterministic
+        acc0 += red[(q * 2 + 0) * 64 + lane];
+        acc1 += red[(q * 2 + 1) * 64 + lane];
+    }
     if constexpr (EPI == EPI_SWIGLU) {
         store4<BF16, EPI>(acc0, acc1, C, bias, residual, fi, ct * 32, fg, ldc);
     } else {
-        store4<BF16, EPI>(acc0, acc0, C, bias, residual, fi, ct * 32, fg, ldc);
-        store4<BF16, EPI>(acc1, acc1, C, bias, residual, fi, ct * 32 + 16, fg, ldc);
+        store4<BF16, EPI>(acc0, acc0, C, bias, residual, fi, ct * COLS, fg, ldc);
+        if constexpr (!HALF) store4<BF16, EPI>(acc1, acc1, C, bias, residual, fi, ct * 32 + 16, fg, ldc);
     }
 }
 
-struct SkinnyWorkspace {
-    float* ws = nullptr;
-    uint32_t* counters = nullptr;
-    size_t bytes = 0;
-    int tiles = 0;
-};
-
-int32_t skinny_workspace(hipStream_t s, size_t bytes, int tiles, SkinnyWorkspace** out) {
-    static std::mutex mu;
-    static std::unordered_map<hipStream_t, SkinnyWorkspace> table;
-    std::lock_guard<std::mutex> lock(mu);
-    SkinnyWorkspace& w = table[s];
-    if (w.bytes < bytes || w.tiles < tiles) {
-        if (w.ws) (void)hipFree(w.ws);
-        if (w.counters) (void)hipFree(w.counters);
-        w = SkinnyWorkspace{};
-        const size_t nb = bytes > (8u << 20) ? bytes : (8u << 20);
-        const int nt = tiles > 4096 ? tiles : 4096;
-        D3D_HIP(hipMalloc(&w.ws, nb));
-        D3D_HIP(hipMalloc(&w.counters, (size_t)nt * sizeof(uint32_t)));
-        D3D_HIP(hipMemset(w.counters, 0, (size_t)nt * sizeof(uint32_t)));
-        w.bytes = nb;
-        w.tiles = nt;
-    }
-    *out = &w;
-    return D3D_OK;
-}
-
-template <bool BF16, int EPI>
+template <bool BF16, int EPI, bool NORM>
 int32_t launch_skinny(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
-                      int64_t ldw, int64_t ldc, hipStream_t s) {
-    const int ntiles = N / 32, nsteps = K / 32;
-    // enough waves for ~4 per SIMD, at least 8 K steps per slice
-    int splits = (4 * 4 * cu_count() + ntiles - 1) / ntiles;
-    if (splits > nsteps / 8) splits = nsteps / 8;
-    if (splits < 1) splits = 1;
-    if (splits > 16) splits = 16;
-    SkinnyWorkspace* w = nullptr;
-    int32_t rc = skinny_workspace(s, (size_t)ntiles * splits * 2048, ntiles, &w);
-    if (rc != D3D_OK) return rc;
-    const int waves = ntiles * splits;
-    hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI>), dim3((waves + 3) / 4), dim3(SK_THREADS), 0, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
-                       (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, splits, w->ws, w->counters);
+                      int64_t ldw, int64_t ldc, const float* norm_w, float eps, hipStream_t s) {
+    const int nsteps = K / 32;
+    const bool half = EPI != EPI_SWIGLU && N / 32 < 2 * cu_count();   // fewer than two 32-column tiles per CU: 16-column tiles (measured:
+                                                                     //   qkv 2.6 -> 3.0 TB/s, down_proj 1.9 -> 2.8 TB/s)
+    const int ntiles = half ? N / 16 : N / 32;
+    int nw = ntiles <= 256 ? 16 : (ntiles <= 512 ? 8 : 4);           // ~2000-4000 waves on the chip, K / 32 / nw steps each
+    while (nw > 1 && nsteps / nw < 2) nw >>= 1;
+    const size_t sh = (size_t)nw * 2 * 64 * 16 + 16 * sizeof(float);
+    if (half) {
+        if constexpr (EPI != EPI_SWIGLU)
+            hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, NORM, true>), dim3(ntiles), dim3(nw * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,
+                               (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, norm_w, eps);
+    } else {
+        hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, NORM, false>), dim3(ntiles), dim3(nw * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,
+                           (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, norm_w, eps);
+    }
     D3D_LAUNCH_CHECK();
+}
+
+template <bool NORM>
+int32_t skinny_dispatch(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
+                        int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, const float* norm_w, float eps, void* stream) {
+    if (M <= 0) return D3D_OK;
+    if (M > 16 || N % 32 != 0 || K % 32 != 0 || (lda & 7) || (ldw & 7) || (ldc & 3)) {
+        d3d_set_error_("skinny GEMM: needs M <= 16, N % 32 == 0, K % 32 == 0, lda/ldw % 8 == 0, ldc % 4 == 0");
+        return D3D_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+#define D3D_SKINNY_CASE(E)                                                                                                    \
+    case E:                                                                                                                   \
+        return dtype == 0 ? launch_skinny<true, E, NORM>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, norm_w, eps, s)      \
+                          : launch_skinny<false, E, NORM>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, norm_w, eps, s);
+    switch (epilogue) {
+        D3D_SKINNY_CASE(EPI_NONE)
+        D3D_SKINNY_CASE(EPI_BIAS)
+        D3D_SKINNY_CASE(EPI_RES)
+        D3D_SKINNY_CASE(EPI_SWIGLU)
+    }
+#undef D3D_SKINNY_CASE
+    d3d_set_error_("skinny GEMM: supported epilogues are none, bias, residual, SwiGLU");
+    return D3D_EINVAL;
 }
 
 }  // namespace
@@ -828,26 +842,7 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
 int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream) {
     if (M <= 0) return D3D_OK;
-    if (tile == 16) {
-        if (M > 16 || N % 32 != 0 || K % 32 != 0 || (lda & 7) || (ldw & 7) || (ldc & 3)) {
-            d3d_set_error_("d3d_gemm_nt_tile: the skinny kernel needs M <= 16, N % 32 == 0, K % 32 == 0, lda/ldw % 8 == 0, ldc % 4 == 0");
-            return D3D_EINVAL;
-        }
-        hipStream_t s16 = (hipStream_t)stream;
-#define D3D_SKINNY_CASE(E)                                                                                            \
-    case E:                                                                                                           \
-        return dtype == 0 ? launch_skinny<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s16)               \
-                          : launch_skinny<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s16);
-        switch (epilogue) {
-            D3D_SKINNY_CASE(EPI_NONE)
-            D3D_SKINNY_CASE(EPI_BIAS)
-            D3D_SKINNY_CASE(EPI_RES)
-            D3D_SKINNY_CASE(EPI_SWIGLU)
-        }
-#undef D3D_SKINNY_CASE
-        d3d_set_error_("d3d_gemm_nt_tile: the skinny kernel supports epilogues none, bias, residual, SwiGLU");
-        return D3D_EINVAL;
-    }
+    if (tile == 16) return skinny_dispatch<false>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, dtype, epilogue, nullptr, 0.f, stream);
     if (tile != 128 && tile != 130 && tile != 132 && tile != 256 && tile != 257 && tile != 258) {
         d3d_set_error_("d3d_gemm_nt_tile: tile must be 128 (130 / 132: 2 / 4 LDS stages forced), 256 (K-half steps), 257 (whole-K-tile steps) or 258 (257 + split-K tail)");
         return D3D_EINVAL;
@@ -887,6 +882,13 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
 #undef D3D_GEMM_CASE
     d3d_set_error_("d3d_gemm_nt: unknown epilogue");
     return D3D_EINVAL;
+}
+
+// C = epi( RMSNorm(A; norm_w, eps) . W^T ) for M <= 16 rows: the norm is applied to the A fragments inside the skinny kernel,
+// bit-identical to d3d_norm(rms = 1) followed by d3d_gemm_nt (HF Phi3RMSNorm -> nn.Linear under generate, VLN-POL:463).
+int32_t d3d_gemm_rmsnorm_nt(const void* A, const float* norm_w, float eps, const void* W, void* C, const void* bias, const void* residual,
+                            int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, void* stream) {
+    return skinny_dispatch<true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, dtype, epilogue, norm_w, eps, stream);
 }
 
 }  // extern "C"

@@ -110,8 +110,8 @@ def attention_packed(qkv3: torch.Tensor, n_heads: int, causal: bool, cu_seqlens:
     return _hip.attention_packed(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid)
 
 
-def decode_attention(qkv_new, prompt_qkv, cu_seqlens, knew, vnew, n_heads: int, t_new: int, max_prompt_len: int):
-    return _hip.decode_attention(qkv_new, prompt_qkv, cu_seqlens, knew, vnew, n_heads, t_new, max_prompt_len)
+def decode_attention(qkv_new, prompt_qkv, cu_seqlens, knew, vnew, n_heads: int, t_new: int, max_prompt_len: int, rope=None):
+    return _hip.decode_attention(qkv_new, prompt_qkv, cu_seqlens, knew, vnew, n_heads, t_new, max_prompt_len, rope)
 
 
 def rope_qk_(qkv: torch.Tensor, n_rot_heads: int, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:

@@ -19,8 +19,9 @@ _lib.register("d3d_set_attention", [vp, vp, i32, i32, i32, i32, vp, vp])
 _lib.register("d3d_flash_attention", [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp])
 _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
 _lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
-_lib.register("d3d_decode_attention", [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])
+_lib.register("d3d_decode_attention", [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp])
 _lib.register("d3d_phi3_decode_token", [vp])
+_lib.register("d3d_gemm_rmsnorm_nt", [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, vp])
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -137,14 +138,26 @@ class HipDense:
         _lib.check(self.lib.d3d_rope_inplace(_p(qkv2d), _p(cos), _p(sin), qkv2d.shape[0], S, n_rot_heads, hd, qkv2d.stride(0), _p(pos),
                                              0 if qkv2d.dtype == torch.bfloat16 else 1, self._stream()))
 
-    def decode_attention(self, qkv_new, prompt_qkv, cu_seqlens, knew, vnew, n_heads, t_new, max_prompt_len):
-        """One KV-cache decode step: qkv_new (B, 3H*hd) rotated; prompt_qkv (T, 3H*hd) the layer's prefill buffer; knew / vnew
-        (B, Tmax, H, hd) side caches (token t_new is appended here).  -> (B, H*hd)."""
+    def decode_attention(self, qkv_new, prompt_qkv, cu_seqlens, knew, vnew, n_heads, t_new, max_prompt_len, rope=None):
+        """One KV-cache decode step: qkv_new (B, 3H*hd) rotated (or un-rotated with rope=(cos, sin, pos)); prompt_qkv (T, 3H*hd) the
+        layer's prefill buffer; knew / vnew (B, Tmax, H, hd) side caches (token t_new is appended here).  -> (B, H*hd)."""
         B = qkv_new.shape[0]
         Tmax, hd = knew.shape[1], knew.shape[3]
         out = torch.empty((B, n_heads * hd), dtype=qkv_new.dtype, device=qkv_new.device)
+        cos, sin, pos = rope if rope is not None else (None, None, None)
         _lib.check(self.lib.d3d_decode_attention(_p(qkv_new), _p(prompt_qkv), _p(cu_seqlens), _p(knew), _p(vnew), _p(out), B, n_heads, hd, t_new, Tmax,
-                                                 max_prompt_len, 0 if qkv_new.dtype == torch.bfloat16 else 1, self._stream()))
+                                                 max_prompt_len, _p(cos), _p(sin), _p(pos), 0 if qkv_new.dtype == torch.bfloat16 else 1, self._stream()))
+        return out
+
+    def rmsnorm_linear(self, x, norm_w, eps, w, residual=None, swiglu=False):
+        """epi(RMSNorm(x) @ w.T) for <= 16 rows in one launch (d3d_gemm_rmsnorm_nt); swiglu expects interleaved gate/up rows."""
+        M, K = x.shape
+        N = w.shape[0]
+        n_out = N // 2 if swiglu else N
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+        epi = EPI["swiglu"] if swiglu else (EPI["res"] if residual is not None else EPI["none"])
+        _lib.check(self.lib.d3d_gemm_rmsnorm_nt(_p(x), _p(norm_w), float(eps), _p(w), _p(out), None, _p(residual), M, N, K, x.stride(0), w.stride(0),
+                                                n_out, 0 if x.dtype == torch.bfloat16 else 1, epi, self._stream()))
         return out
 
     def phi3_decode_token(self, args: "Phi3DecodeArgs"):

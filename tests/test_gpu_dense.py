@@ -122,6 +122,17 @@ def test_gemm_skinny_decode_rows(hd, dt, tol):
             if N % 32 == 0 and (N // 2) % 16 == 0:
                 assert rel(hd.linear_swiglu(x, interleave_gate_up(w)).float(), y32[:, N // 2:] * F.silu(y32[:, :N // 2])) < tol, (M, N, K, "swiglu")
         assert torch.equal(hd.linear(x, w, None, None, r), hd.linear(x, w, None, None, r))
+    # RMSNorm folded into the projection: bit-identical to the norm kernel followed by the projection
+    for M, N, K in ((8, 9216, 3072), (3, 1024, 512), (16, 2048, 1024)):
+        x = (torch.randn(M, K, device="cuda") * 2.0).to(dt)
+        w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
+        g = torch.rand(K, device="cuda") + 0.5
+        r = torch.randn(M, N, device="cuda").to(dt)
+        h = hd.rms_norm(x, g, 1e-5)
+        assert torch.equal(hd.rmsnorm_linear(x, g, 1e-5, w), hd.linear(h, w, None, None))
+        assert torch.equal(hd.rmsnorm_linear(x, g, 1e-5, w, residual=r), hd.linear(h, w, None, None, r))
+        wi = interleave_gate_up(w)
+        assert torch.equal(hd.rmsnorm_linear(x, g, 1e-5, wi, swiglu=True), hd.linear_swiglu(h, wi))
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
@@ -226,3 +237,42 @@ def test_flash_attention_packed_ragged(hd, dt, tol, causal):
         assert rel(out[o:o + n], ref) < tol, (n, rel(out[o:o + n], ref))
         o += n
     assert float(out[T:].abs().max()) == 0.0                     # padding rows untouched
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 6e-3), (torch.float16, 1e-3)])
+def test_decode_attention_kv_cache(hd, dt, tol):
+    """d3d_decode_attention: one query per sequence over [prompt keys read in place from a packed QKV buffer | side cache | the
+    current token], ragged prompts, several decode steps; vs fp32 softmax attention over the same (16-bit) keys and values.  The
+    fused-RoPE form (un-rotated q, k + cos/sin/pos) must give what rope_inplace followed by the plain form gives."""
+    torch.manual_seed(6)
+    H, d, Tmax = 4, 96, 5
+    lens = [1, 63, 300, 129]
+    B, T = len(lens), sum(lens)
+    prompt = (torch.randn(T + 7, 3 * H, d, device="cuda") * 0.8).to(dt)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32, device="cuda") / d))
+    ang = torch.arange(max(lens) + Tmax + 1, dtype=torch.float32, device="cuda")[:, None] * inv[None]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    lens_d = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    kn_a, vn_a = (torch.zeros(B, Tmax, H, d, dtype=dt, device="cuda") for _ in range(2))
+    kn_b, vn_b = (torch.zeros(B, Tmax, H, d, dtype=dt, device="cuda") for _ in range(2))
+    new_k, new_v = [], []
+    for t in range(Tmax):
+        raw = (torch.randn(B, 3 * H, d, device="cuda") * 0.8).to(dt)
+        pos = (lens_d + t).contiguous()
+        rot = raw.clone().view(B, 3 * H * d)
+        hd.rope_inplace(rot, cos, sin, 1, 2 * H, d, pos)
+        rot = rot.view(B, 3 * H, d)
+        out_a = hd.decode_attention(rot.view(B, -1), prompt.view(T + 7, -1), cu, kn_a, vn_a, H, t, max(lens)).float().view(B, H, d)
+        out_b = hd.decode_attention(raw.view(B, -1), prompt.view(T + 7, -1), cu, kn_b, vn_b, H, t, max(lens), rope=(cos, sin, pos)).float().view(B, H, d)
+        new_k.append(rot[:, H:2 * H].float())
+        new_v.append(rot[:, 2 * H:].float())
+        for b, n in enumerate(lens):
+            o = int(cu[b])
+            k = torch.cat([prompt[o:o + n, H:2 * H].float()] + [x[b][None] for x in new_k], 0)            # (L,H,d)
+            v = torch.cat([prompt[o:o + n, 2 * H:].float()] + [x[b][None] for x in new_v], 0)
+            q = rot[b, :H].float()                                                                        # (H,d)
+            p = torch.softmax(torch.einsum("hd,lhd->hl", q, k) / d ** 0.5, -1)
+            ref = torch.einsum("hl,lhd->hd", p, v)
+            assert rel(out_a[b], ref) < tol, (t, b, rel(out_a[b], ref))
+        assert rel(out_b, out_a) < 1e-3 and torch.equal(kn_a[:, :t + 1], kn_b[:, :t + 1]) and torch.equal(vn_a[:, :t + 1], vn_b[:, :t + 1])
