@@ -656,84 +656,72 @@ int32_t launch(const void* A, const void* W, void* C, const void* bias, const vo
 // sums them in wave order (deterministic) and runs the epilogue.  (A first version cut K across workgroups with fp32 partials
 // in global memory and an arrival counter: 6 us of fix-up on a 12 us o_proj.)  SwiGLU uses the per-16 interleaved gate/up
 // rows: the two fragments ARE a gate tile and its up tile.
-// NORM: the RMSNorm in front of the projection is applied to the x fragments on the fly -- rstd per row by one wave per row with
-// exactly k_norm's summation order, then bf16((x * rstd) * g) element by element, so the result is bit-identical to running
-// d3d_norm first -- which removes two launches of ~9 us per layer from the decode token.
+// (Folding the preceding RMSNorm into the x fragments was built and measured -- bit-identical, but the per-step gain loads and
+// the row-statistics prologue cost 13-31 us per projection against 9 us for the separate norm launch; dropped.)
 // ================================================================================================
 // HALF: 16 instead of 32 columns per workgroup (twice as many workgroups: the narrow o_proj / down_proj then cover 192 CUs, not 96)
-template <bool BF16, int EPI, bool NORM, bool HALF>
+template <bool BF16, int EPI, bool HALF>
 __global__ void __launch_bounds__(1024)
 k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
-              const uint16_t* __restrict__ residual, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldc, const float* __restrict__ norm_w,
-              float eps) {
-    extern __shared__ __attribute__((aligned(16))) float sk_lds[];      // [NW][2][64] float4, then rstd[16]
+              const uint16_t* __restrict__ residual, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldc) {
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];      // [NW][2][64] float4
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
     const int fi = lane & 15, fg = lane >> 4;
     const int ct = blockIdx.x;
     const int nsteps = K / 32;
     const int s0 = (int)((int64_t)wave * nsteps / NW), s1 = (int)((int64_t)(wave + 1) * nsteps / NW);
     float4v* red = reinterpret_cast<float4v*>(sk_lds);
-    float* rs = sk_lds + NW * 2 * 64 * 4;
-    float my_r = 1.f;
-    if constexpr (NORM) {
-        for (int m = wave; m < M; m += NW) {                   // one wave per row, k_norm's lane mapping and reduction order
-            const uint16_t* xr0 = X + (int64_t)m * ldx;
-            float ss = 0.f;
-            for (int off = lane * 8; off < K; off += 512) {
-                const uint4 raw = *reinterpret_cast<const uint4*>(xr0 + off);
-                const uint16_t* hh = reinterpret_cast<const uint16_t*>(&raw);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float v = to_f32<BF16>(hh[q]);
-                    ss += v * v;
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-            if (lane == 0) rs[m] = rsqrtf(ss / (float)K + eps);
-        }
-        __syncthreads();
-        my_r = rs[fi < M ? fi : M - 1];
-    }
     constexpr int COLS = HALF ? 16 : 32;
     const uint16_t* w0 = W + (int64_t)(ct * COLS + fi) * ldw + fg * 8;
     const uint16_t* w1 = HALF ? w0 : w0 + 16 * ldw;
-    const uint16_t* xr = X + (int64_t)(fi < M ? fi : M - 1) * ldx + fg * 8;      // rows >= M: a duplicate, never stored
-    const float* gr = norm_w + fg * 8;
-    auto xfrag = [&](int st) -> uint4 {
-        uint4 x = *reinterpret_cast<const uint4*>(xr + st * 32);
-        if constexpr (NORM) {
-            const float4 g0 = *reinterpret_cast<const float4*>(gr + st * 32), g1 = *reinterpret_cast<const float4*>(gr + st * 32 + 4);
-            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            uint16_t* e = reinterpret_cast<uint16_t*>(&x);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) e[q] = from_f32<BF16>(to_f32<BF16>(e[q]) * my_r * gg[q]);
-        }
-        return x;
-    };
-    float4v acc0 = float4v{0.f, 0.f, 0.f, 0.f}, acc1 = float4v{0.f, 0.f, 0.f, 0.f};
+    uint4 a[4], b[4];
     int st = s0;
-    for (; st + 4 <= s1; st += 4) {                            // 12 independent 16-byte loads in flight per lane
-        uint4 a[4], b[4], x[4];
+    const bool first = st + 4 <= s1;
+    if (first) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             a[u] = *reinterpret_cast<const uint4*>(w0 + (st + u) * 32);
             if constexpr (!HALF) b[u] = *reinterpret_cast<const uint4*>(w1 + (st + u) * 32);
-            x[u] = xfrag(st + u);
         }
+    }
+    const uint16_t* xr = X + (int64_t)(fi < M ? fi : M - 1) * ldx + fg * 8;      // rows >= M: a duplicate, never stored
+    auto xfrag = [&](int stp) -> uint4 { return *reinterpret_cast<const uint4*>(xr + stp * 32); };
+    float4v acc0 = float4v{0.f, 0.f, 0.f, 0.f}, acc1 = float4v{0.f, 0.f, 0.f, 0.f};
+    if (first) {
+        for (;;) {                                             // software pipeline: batch i+1's weights load under batch i's MFMAs
+            uint4 x[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc0 = mfma16<BF16>(a[u], x[u], acc0);
-            if constexpr (!HALF) acc1 = mfma16<BF16>(b[u], x[u], acc1);
+            for (int u = 0; u < 4; ++u) x[u] = xfrag(st + u);
+            const bool more = st + 8 <= s1;
+            uint4 an[4], bn[4];
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    an[u] = *reinterpret_cast<const uint4*>(w0 + (st + 4 + u) * 32);
+                    if constexpr (!HALF) bn[u] = *reinterpret_cast<const uint4*>(w1 + (st + 4 + u) * 32);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc0 = mfma16<BF16>(a[u], x[u], acc0);
+                if constexpr (!HALF) acc1 = mfma16<BF16>(b[u], x[u], acc1);
+            }
+            st += 4;
+            if (!more) break;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = an[u];
+                if constexpr (!HALF) b[u] = bn[u];
+            }
         }
     }
     for (; st < s1; ++st) {
-        const uint4 a = *reinterpret_cast<const uint4*>(w0 + st * 32);
+        const uint4 aw = *reinterpret_cast<const uint4*>(w0 + st * 32);
         const uint4 x = xfrag(st);
-        acc0 = mfma16<BF16>(a, x, acc0);
+        acc0 = mfma16<BF16>(aw, x, acc0);
         if constexpr (!HALF) {
-            const uint4 b = *reinterpret_cast<const uint4*>(w1 + st * 32);
-            acc1 = mfma16<BF16>(b, x, acc1);
+            const uint4 bw = *reinterpret_cast<const uint4*>(w1 + st * 32);
+            acc1 = mfma16<BF16>(bw, x, acc1);
         }
     }
     red[(wave * 2 + 0) * 64 + lane] = acc0;
@@ -754,30 +742,29 @@ k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, ui
     }
 }
 
-template <bool BF16, int EPI, bool NORM>
+template <bool BF16, int EPI>
 int32_t launch_skinny(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
-                      int64_t ldw, int64_t ldc, const float* norm_w, float eps, hipStream_t s) {
+                      int64_t ldw, int64_t ldc, hipStream_t s) {
     const int nsteps = K / 32;
     const bool half = EPI != EPI_SWIGLU && N / 32 < 2 * cu_count();   // fewer than two 32-column tiles per CU: 16-column tiles (measured:
                                                                      //   qkv 2.6 -> 3.0 TB/s, down_proj 1.9 -> 2.8 TB/s)
     const int ntiles = half ? N / 16 : N / 32;
     int nw = ntiles <= 256 ? 16 : (ntiles <= 512 ? 8 : 4);           // ~2000-4000 waves on the chip, K / 32 / nw steps each
     while (nw > 1 && nsteps / nw < 2) nw >>= 1;
-    const size_t sh = (size_t)nw * 2 * 64 * 16 + 16 * sizeof(float);
+    const size_t sh = (size_t)nw * 2 * 64 * 16;
     if (half) {
         if constexpr (EPI != EPI_SWIGLU)
-            hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, NORM, true>), dim3(ntiles), dim3(nw * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,
-                               (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, norm_w, eps);
+            hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, true>), dim3(ntiles), dim3(nw * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,
+                               (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc);
     } else {
-        hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, NORM, false>), dim3(ntiles), dim3(nw * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,
-                           (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, norm_w, eps);
+        hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, false>), dim3(ntiles), dim3(nw * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,
+                           (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc);
     }
     D3D_LAUNCH_CHECK();
 }
 
-template <bool NORM>
 int32_t skinny_dispatch(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
-                        int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, const float* norm_w, float eps, void* stream) {
+                        int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, void* stream) {
     if (M <= 0) return D3D_OK;
     if (M > 16 || N % 32 != 0 || K % 32 != 0 || (lda & 7) || (ldw & 7) || (ldc & 3)) {
         d3d_set_error_("skinny GEMM: needs M <= 16, N % 32 == 0, K % 32 == 0, lda/ldw % 8 == 0, ldc % 4 == 0");
@@ -786,8 +773,8 @@ int32_t skinny_dispatch(const void* A, const void* W, void* C, const void* bias,
     hipStream_t s = (hipStream_t)stream;
 #define D3D_SKINNY_CASE(E)                                                                                                    \
     case E:                                                                                                                   \
-        return dtype == 0 ? launch_skinny<true, E, NORM>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, norm_w, eps, s)      \
-                          : launch_skinny<false, E, NORM>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, norm_w, eps, s);
+        return dtype == 0 ? launch_skinny<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)                         \
+                          : launch_skinny<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);
     switch (epilogue) {
         D3D_SKINNY_CASE(EPI_NONE)
         D3D_SKINNY_CASE(EPI_BIAS)
@@ -842,7 +829,7 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
 int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream) {
     if (M <= 0) return D3D_OK;
-    if (tile == 16) return skinny_dispatch<false>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, dtype, epilogue, nullptr, 0.f, stream);
+    if (tile == 16) return skinny_dispatch(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, dtype, epilogue, stream);
     if (tile != 128 && tile != 130 && tile != 132 && tile != 256 && tile != 257 && tile != 258) {
         d3d_set_error_("d3d_gemm_nt_tile: tile must be 128 (130 / 132: 2 / 4 LDS stages forced), 256 (K-half steps), 257 (whole-K-tile steps) or 258 (257 + split-K tail)");
         return D3D_EINVAL;
@@ -882,13 +869,6 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
 #undef D3D_GEMM_CASE
     d3d_set_error_("d3d_gemm_nt: unknown epilogue");
     return D3D_EINVAL;
-}
-
-// C = epi( RMSNorm(A; norm_w, eps) . W^T ) for M <= 16 rows: the norm is applied to the A fragments inside the skinny kernel,
-// bit-identical to d3d_norm(rms = 1) followed by d3d_gemm_nt (HF Phi3RMSNorm -> nn.Linear under generate, VLN-POL:463).
-int32_t d3d_gemm_rmsnorm_nt(const void* A, const float* norm_w, float eps, const void* W, void* C, const void* bias, const void* residual,
-                            int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, void* stream) {
-    return skinny_dispatch<true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, dtype, epilogue, norm_w, eps, stream);
 }
 
 }  // extern "C"

@@ -1,5 +1,5 @@
-// phi3_decode.cpp -- host side of one KV-cache decode token of the Phi-3 decoder stack: the five launches of every layer
-// (RMSNorm+qkv GEMM, RoPE+decode attention, o_proj + residual, RMSNorm+gate_up+SwiGLU, down_proj + residual) are issued
+// phi3_decode.cpp -- host side of one KV-cache decode token of the Phi-3 decoder stack: the seven launches of every layer
+// (RMSNorm, qkv GEMM, RoPE + decode attention, o_proj + residual, RMSNorm, gate_up + SwiGLU, down_proj + residual) are issued
 // from C++ in one call.  At 8 rows a launch runs for 5-60 us, so issuing ~260 of them per token from Python (ctypes + tensor
 // allocation, ~15 us each) left the GPU idle most of the time.  Reference: the decoder layers under
 // `llava.generate(..., do_sample=False)` (VLN-POL:463; HF Phi3DecoderLayer with use_cache).
@@ -26,16 +26,18 @@ extern "C" int32_t d3d_phi3_decode_token(const d3d_phi3_decode_args* a) {
         if (rc != D3D_OK) return rc; \
     } while (0)
     for (int32_t l = 0; l < a->n_layers; ++l) {
-        // input_layernorm is applied inside the qkv projection, post_attention_layernorm inside gate_up (bit-identical to d3d_norm first)
-        D3D_TRY(d3d_gemm_rmsnorm_nt(x, a->n1[l], a->rms_eps, a->qkv_w[l], a->qkv, nullptr, nullptr, B, (int32_t)qkv_w, Hd, Hd, Hd, qkv_w, dt, 0, s));
+        D3D_TRY(d3d_norm(x, a->n1[l], nullptr, a->h, B, Hd, Hd, Hd, a->rms_eps, 1, dt, s));
+        D3D_TRY(d3d_gemm_nt(a->h, a->qkv_w[l], a->qkv, nullptr, nullptr, B, (int32_t)qkv_w, Hd, Hd, Hd, qkv_w, dt, 0, s));
         D3D_TRY(d3d_decode_attention(a->qkv, a->prompt_qkv[l], a->cu_seqlens, (char*)a->knew + (int64_t)l * a->cache_layer_stride_bytes,
                                      (char*)a->vnew + (int64_t)l * a->cache_layer_stride_bytes, a->attn, B, H, hd, a->t_new, a->t_max,
                                      a->max_prompt_len, a->cos_t, a->sin_t, a->pos, dt, s));                      // RoPE of q, k inside
         D3D_TRY(d3d_gemm_nt(a->attn, a->o_w[l], x, nullptr, x, B, Hd, Hd, Hd, Hd, Hd, dt, 4, s));                 // + residual, in place
-        D3D_TRY(d3d_gemm_rmsnorm_nt(x, a->n2[l], a->rms_eps, a->gate_up_w[l], a->act, nullptr, nullptr, B, 2 * I, Hd, Hd, Hd, I, dt, 6, s));   // SwiGLU
+        D3D_TRY(d3d_norm(x, a->n2[l], nullptr, a->h, B, Hd, Hd, Hd, a->rms_eps, 1, dt, s));
+        D3D_TRY(d3d_gemm_nt(a->h, a->gate_up_w[l], a->act, nullptr, nullptr, B, 2 * I, Hd, Hd, Hd, I, dt, 6, s));  // SwiGLU (interleaved rows)
         D3D_TRY(d3d_gemm_nt(a->act, a->down_w[l], x, nullptr, x, B, Hd, I, I, I, Hd, dt, 4, s));                   // + residual, in place
     }
-    D3D_TRY(d3d_gemm_rmsnorm_nt(x, a->norm_w, a->rms_eps, a->lm_head_w, a->logits, nullptr, nullptr, B, a->vocab, Hd, Hd, Hd, a->vocab, dt, 0, s));
+    D3D_TRY(d3d_norm(x, a->norm_w, nullptr, a->h, B, Hd, Hd, Hd, a->rms_eps, 1, dt, s));
+    D3D_TRY(d3d_gemm_nt(a->h, a->lm_head_w, a->logits, nullptr, nullptr, B, a->vocab, Hd, Hd, Hd, a->vocab, dt, 0, s));
 #undef D3D_TRY
     return D3D_OK;
 }

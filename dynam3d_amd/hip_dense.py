@@ -21,7 +21,6 @@ _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
 _lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
 _lib.register("d3d_decode_attention", [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp])
 _lib.register("d3d_phi3_decode_token", [vp])
-_lib.register("d3d_gemm_rmsnorm_nt", [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, vp])
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -147,17 +146,6 @@ class HipDense:
         cos, sin, pos = rope if rope is not None else (None, None, None)
         _lib.check(self.lib.d3d_decode_attention(_p(qkv_new), _p(prompt_qkv), _p(cu_seqlens), _p(knew), _p(vnew), _p(out), B, n_heads, hd, t_new, Tmax,
                                                  max_prompt_len, _p(cos), _p(sin), _p(pos), 0 if qkv_new.dtype == torch.bfloat16 else 1, self._stream()))
-        return out
-
-    def rmsnorm_linear(self, x, norm_w, eps, w, residual=None, swiglu=False):
-        """epi(RMSNorm(x) @ w.T) for <= 16 rows in one launch (d3d_gemm_rmsnorm_nt); swiglu expects interleaved gate/up rows."""
-        M, K = x.shape
-        N = w.shape[0]
-        n_out = N // 2 if swiglu else N
-        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
-        epi = EPI["swiglu"] if swiglu else (EPI["res"] if residual is not None else EPI["none"])
-        _lib.check(self.lib.d3d_gemm_rmsnorm_nt(_p(x), _p(norm_w), float(eps), _p(w), _p(out), None, _p(residual), M, N, K, x.stride(0), w.stride(0),
-                                                n_out, 0 if x.dtype == torch.bfloat16 else 1, epi, self._stream()))
         return out
 
     def phi3_decode_token(self, args: "Phi3DecodeArgs"):

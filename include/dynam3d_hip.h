@@ -213,11 +213,6 @@ int32_t d3d_decode_attention(const void* qkv_new_d, const void* prompt_qkv_d, co
                              void* out_d, int32_t B, int32_t H, int32_t head_dim, int32_t t_new, int32_t Tmax, int32_t max_prompt_len,
                              const float* cos_d, const float* sin_d, const int32_t* pos_d /* all three or none: fused RoPE of q, k */,
                              int32_t dtype, void* stream);
-/* C = epi(RMSNorm(A; norm_w, eps) . W^T) for M <= 16 rows (KV-cache decode): Phi3RMSNorm -> nn.Linear in one launch, bit-identical
- * to d3d_norm(rms = 1) + d3d_gemm_nt.  N % 32 == 0, K % 32 == 0; epilogues 0 / 1 / 4 / 6. */
-int32_t d3d_gemm_rmsnorm_nt(const void* A_d, const float* norm_w_d, float eps, const void* W_d, void* C_d, const void* bias_d,
-                            const void* residual_d, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype,
-                            int32_t epilogue, void* stream);
 /* LayerNorm (rms = 0; clip/model.py:153-159: float32 statistics) or RMSNorm (rms = 1; Phi-3) over rows of D <= 4096 */
 int32_t d3d_norm(const void* x_d, const float* w_d, const float* b_d, void* y_d, int32_t rows, int32_t D, int64_t ldx,
                  int64_t ldy, float eps, int32_t rms, int32_t dtype, void* stream);

@@ -122,17 +122,6 @@ def test_gemm_skinny_decode_rows(hd, dt, tol):
             if N % 32 == 0 and (N // 2) % 16 == 0:
                 assert rel(hd.linear_swiglu(x, interleave_gate_up(w)).float(), y32[:, N // 2:] * F.silu(y32[:, :N // 2])) < tol, (M, N, K, "swiglu")
         assert torch.equal(hd.linear(x, w, None, None, r), hd.linear(x, w, None, None, r))
-    # RMSNorm folded into the projection: bit-identical to the norm kernel followed by the projection
-    for M, N, K in ((8, 9216, 3072), (3, 1024, 512), (16, 2048, 1024)):
-        x = (torch.randn(M, K, device="cuda") * 2.0).to(dt)
-        w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
-        g = torch.rand(K, device="cuda") + 0.5
-        r = torch.randn(M, N, device="cuda").to(dt)
-        h = hd.rms_norm(x, g, 1e-5)
-        assert torch.equal(hd.rmsnorm_linear(x, g, 1e-5, w), hd.linear(h, w, None, None))
-        assert torch.equal(hd.rmsnorm_linear(x, g, 1e-5, w, residual=r), hd.linear(h, w, None, None, r))
-        wi = interleave_gate_up(w)
-        assert torch.equal(hd.rmsnorm_linear(x, g, 1e-5, wi, swiglu=True), hd.linear_swiglu(h, wi))
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])

@@ -27,5 +27,6 @@ for name, N, K, epi in (("qkv", 9216, 3072, "none"), ("o", 3072, 3072, "res"), (
         return hd.linear(x, w, None, None, r if epi == "res" else None)
     t = timeit(f, 48)
     tot += t if name != "lm_head" else 0
-    print(f"{name:8s} N={N} K={K}: {t * 1e3:.1f} us  {N * K * 2 / t / 1e9:.2f} TB/s", flush=True)
+    extra = ""
+    print(f"{name:8s} N={N} K={K}: {t * 1e3:.1f} us  {N * K * 2 / t / 1e9:.2f} TB/s{extra}", flush=True)
 print(f"layer sum {tot * 1e3:.1f} us -> x32 = {tot * 32:.2f} ms/token")
