@@ -70,3 +70,24 @@ class StepOracle:
         self.timing["phi3_prefill"] = time.time() - t0
         self.last_embeds, self.last_lengths = emb, lengths
         return lo.numpy()
+
+    @torch.no_grad()
+    def generate(self, rgb, depth, instructions, positions, headings, patch_segm, max_new_tokens: int = 20) -> List[str]:
+        """The call the reference's trainer actually makes (VLN-POL:329 -> List[str]): build the prompt, greedy generation by
+        re-running the prefix (towers_ref.phi3_greedy_decode), cut at '<|end|>', push the text into the action history
+        (VLN-POL:463-468)."""
+        emb, lengths = self.build_inputs(rgb, depth, instructions, positions, headings, patch_segm)
+        c = self.llm
+        end_id = self.tok.SPECIAL["<|end|>"] % c.vocab
+        toks, _ = TR.phi3_greedy_decode(emb, lengths, self.sd, c.layers, c.heads, c.kv_heads, max_new_tokens, end_id, c.rms_eps, c.rope_theta)
+        self.last_tokens = toks
+        texts = []
+        for b, ids in enumerate(toks):
+            t = self.tok.decode(ids)
+            cut = t.find("<|end|>")
+            t = t[:cut] if cut >= 0 else t
+            texts.append(t)
+            self.history[b].pop(0)
+            self.history[b].append(t + "\n")
+        return texts
+

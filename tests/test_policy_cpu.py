@@ -39,3 +39,24 @@ def run_policy_vs_oracle(ops, device, cfg, steps=3, B=2, tol=2e-4, check_embeds=
 
 def test_policy_host_logic_matches_step_oracle():
     run_policy_vs_oracle(CpuOps(), "cpu", SMALL)
+
+
+def test_policy_forward_text_matches_oracle_generation():
+    """`policy.net(...) -> List[str]` (VLN-POL:329) against the oracle's greedy generation, two steps so that the generated
+    text of step 1 is part of step 2's prompt through the action history (VLN-POL:466-468)."""
+    cfg, B = SMALL, 2
+    sd = synth_policy_weights(cfg, seed=0)
+    net = Dynam3D_VLN(cfg, sd, device="cpu", batch_size=B, ops=CpuOps(), max_steps=3)
+    net.feature_fields.initialize_camera_setting(90.0, 90.0)
+    orc = StepOracle(sd, cfg.vit, cfg.llm, B, SyntheticTokenizer(cfg.llm.vocab))
+    ep = SyntheticEpisodes(B, seed=5, image_hw=224, depth_hw=224)
+    instr = [INSTRUCTION_64] * B
+    for _ in range(2):
+        fr = ep.next()
+        pos, hd = [p.tolist() for p in fr.positions], list(fr.headings)
+        got = net({"rgb": torch.from_numpy(fr.rgb), "depth": torch.from_numpy(fr.depth)}, instr, pos, hd, patch_segm=fr.patch_segm, max_new_tokens=3)
+        ref = orc.generate(fr.rgb, fr.depth, instr, pos, hd, fr.patch_segm, max_new_tokens=3)
+        assert got == ref, (got, ref)
+        assert [h[-1] for h in net.feature_fields.history_actions] == [h[-1] for h in orc.history]
+        assert net.convert_text_to_action(got) == net.convert_text_to_action(ref)
+
