@@ -2,7 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Tuple
+from typing import Tuple
 
 import numpy as np
 

@@ -8,7 +8,6 @@ Shapes: activations are row-major (tokens, features); weights are [out, in] like
 """
 from __future__ import annotations
 
-import math
 from typing import Optional, Sequence
 
 import torch

@@ -6,7 +6,7 @@ Float32 end to end (the reference's Feature_Fields parameters are fp32; merge de
 argmax, so the token builder is kept at full precision -- it is <1 % of the step's FLOPs)."""
 from __future__ import annotations
 
-from typing import Dict, List, Sequence
+from typing import Dict, Sequence
 
 import numpy as np
 import torch

@@ -15,7 +15,6 @@ Weights arrive under the reference checkpoints' own key names (OpenAI CLIP `visu
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 from typing import Dict, Optional
 
