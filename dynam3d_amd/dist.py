@@ -51,4 +51,7 @@ def max_over_ranks(x: float, device="cpu") -> float:
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])      # pin the collective to this rank's GPU
+        else:
+            dist.barrier()
