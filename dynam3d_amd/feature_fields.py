@@ -42,9 +42,15 @@ def _args_namespace():
 class Feature_Fields:
     def __init__(self, batch_size: int = 1, device="cuda", state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  compat: str = "reference", max_steps: int = 64, max_views: int = 1, m_cap: int = 4096, z_cap: int = 2048,
-                 ops=None, segmenter=None):
+                 ops=None, segmenter=None, variant: str = "vln"):
+        """variant: "vln" = the VLN class's argument defaults (VLN-FF:22-46, 2 merge proposals); "pretrain" = the Pretrain
+        class's (PRE-FF:29-45: `num_proposal_instances` 4) -- the memory update itself is the same state machine."""
         self.device = torch.device(device)
         self.args = _args_namespace()
+        if variant not in ("vln", "pretrain"):
+            raise ValueError("variant must be 'vln' or 'pretrain'")
+        if variant == "pretrain":
+            self.args.num_proposal_instances = 4
         if ops is None:
             from .ops import HipOps
             ops = HipOps()                      # raises if libdynam3d_hip.so is missing: no CPU fallback
@@ -153,6 +159,14 @@ class Feature_Fields:
             x = torch.from_numpy(np.ascontiguousarray(x))
         return x.to(self.device, dtype=dtype, non_blocking=True).contiguous()
 
+    @staticmethod
+    def _view_ids(view_ids):
+        if view_ids is None:
+            return None
+        if isinstance(view_ids, torch.Tensor):
+            view_ids = view_ids.cpu().numpy()
+        return [int(v) for v in np.asarray(view_ids).reshape(-1)]
+
     def _poses(self, positions, headings, envs, view_offset=0.0) -> torch.Tensor:
         return self._f32(np.stack([make_pose(positions[e], view_offset + float(headings[e])) for e in envs]))
 
@@ -177,9 +191,14 @@ class Feature_Fields:
     # ---- a4 + cascade (VLN-FF:329-396) ---------------------------------------------------------------
     @torch.no_grad()
     def delete_old_features_from_camera_frustum(self, batch_depth, batch_position=None, batch_heading=None,
-                                                batch_camera_intrinsic=None, batch_extrinsic=None, num_of_views=1):
+                                                batch_camera_intrinsic=None, batch_extrinsic=None, num_of_views=1, view_ids=None):
+        """`view_ids` is the Pretrain variant's keyword (PRE-FF:674): V = len(view_ids) and view ix is culled along
+        heading - view_ids[ix]*pi/6 (PRE-FF:696); `num_of_views` is the VLN variant's (no per-view offset, VLN-FF:347)."""
         if batch_extrinsic is not None:
             raise NotImplementedError("intrinsics/extrinsics (non-Habitat datasets) path: SURVEY.md 8f-2")
+        view_ids = self._view_ids(view_ids)
+        if view_ids is not None:
+            num_of_views = len(view_ids)
         depth = self._dev(batch_depth)                                  # (B,V,Hd,Wd) metres
         B, st, pools = self.batch_size, self.state, self.pools
         Hd, Wd = depth.shape[-2], depth.shape[-1]
@@ -191,7 +210,8 @@ class Feature_Fields:
             if not envs:
                 continue
             n_rows = [st.count(e, st.ROWS) for e in envs]
-            pose = self._poses(batch_position, batch_heading, envs)        # no per-view offset (VLN-FF:347)
+            pose = self._poses(batch_position, batch_heading, envs,        # VLN: no per-view offset (VLN-FF:347)
+                               view_offset=0.0 if view_ids is None else view_ids[ix] * (-math.pi / 6))
             slot = self._i32([self.slots[e] for e in envs])
             hits = torch.empty((len(envs), max(n_rows)), dtype=torch.int32, device=self.device)
             n_hits = torch.zeros((len(envs),), dtype=torch.int32, device=self.device)
@@ -229,9 +249,17 @@ class Feature_Fields:
     @torch.no_grad()
     def update_feature_fields(self, batch_depth, batch_grid_ft, batch_image=None, batch_position=None, batch_heading=None,
                               batch_camera_intrinsic=None, batch_rot=None, batch_trans=None, depth_scale=1000.0,
-                              depth_trunc=1000.0, num_of_views=1, patch_segm=None):
+                              depth_trunc=1000.0, num_of_views=1, patch_segm=None, view_ids=None, batch_image_ft=None,
+                              is_training=False):
+        """`num_of_views` (VLN-FF:493: view ix at heading - ix*pi/6) or `view_ids` (PRE-FF:843,920: view ix at
+        heading - view_ids[ix]*pi/6, e.g. [0,3,6,9] = the four 90-degree views of `Net_3DFF.forward`, PRE-POL:160)."""
         if batch_camera_intrinsic is not None:
             raise NotImplementedError("Open3D / intrinsics path (non-Habitat datasets): SURVEY.md 8f-2")
+        if is_training:
+            raise NotImplementedError("pre-training losses: SURVEY.md 8f-1")
+        view_ids = self._view_ids(view_ids)
+        if view_ids is not None:
+            num_of_views = len(view_ids)
         if self.dense is None:
             raise RuntimeError("Feature_Fields has no weights: call load_state_dict first")
         B, V, P, st, pools, ops = self.batch_size, num_of_views, self.P, self.state, self.pools, self.ops
@@ -261,7 +289,8 @@ class Feature_Fields:
             rb, k0, has_tree = zip(*[st.begin_view(e) for e in envs])
             k0 = [k if t else 0 for k, t in zip(k0, has_tree)]
             row_base = self._i32(rb)
-            pose = self._poses(batch_position, batch_heading, envs, view_offset=ix * (-math.pi / 6))   # VLN-FF:550
+            pose = self._poses(batch_position, batch_heading, envs,                                     # VLN-FF:550 / PRE-FF:920
+                               view_offset=(ix if view_ids is None else view_ids[ix]) * (-math.pi / 6))
             ops.unproject_append(depth24[:, ix].contiguous(), pose, slot, row_base, cam, pools)
             ops.append_fts(grid[:, ix].contiguous(), slot, row_base, pools)
 

@@ -110,15 +110,19 @@ class FeatureFieldsOracle:
         return G.mean_rows_f64(x)
 
     # ---- a4 + cascade: delete_old_features_from_camera_frustum (VLN-FF:329-396) ---------------
-    def delete_old_features_from_camera_frustum(self, batch_depth, batch_position, batch_heading, num_of_views=1):
-        """batch_depth (B,V,Hd,Wd) metres (already preprocess_depth'ed)."""
+    def delete_old_features_from_camera_frustum(self, batch_depth, batch_position, batch_heading, num_of_views=1, view_ids=None):
+        """batch_depth (B,V,Hd,Wd) metres (already preprocess_depth'ed).  `view_ids` = the Pretrain variant's signature
+        (PRE-FF:674-696): view ix looks along heading - view_ids[ix]*pi/6 in the cull as well."""
         batch_depth = np.asarray(batch_depth, F32)
+        if view_ids is not None:
+            num_of_views = len(view_ids)
         for b, e in enumerate(self.env):
             for ix in range(num_of_views):
                 if e.pos.shape[0] == 0:
                     continue
-                # NB: the reference does not add the per-view heading offset here (VLN-FF:347)
-                mask = G.frustum_mask_habitat(e.pos, batch_depth[b, ix], batch_position[b], batch_heading[b],
+                # NB: the VLN variant does not add the per-view heading offset here (VLN-FF:347); the Pretrain one does (PRE-FF:696)
+                off = 0.0 if view_ids is None else int(view_ids[ix]) * (-math.pi / 6)
+                mask = G.frustum_mask_habitat(e.pos, batch_depth[b, ix], batch_position[b], off + batch_heading[b],
                                               self.hfov, self.vfov, 0.0, self.far, 0.1)
                 e.pos[mask] = G.TOMBSTONE
                 e.fts[mask] = 0
@@ -146,10 +150,15 @@ class FeatureFieldsOracle:
 
     # ---- update_feature_fields (VLN-FF:493-815) -----------------------------------------------
     @torch.no_grad()
-    def update_feature_fields(self, batch_depth24, batch_grid_ft, patch_segm, batch_position, batch_heading, num_of_views=1):
+    def update_feature_fields(self, batch_depth24, batch_grid_ft, patch_segm, batch_position, batch_heading, num_of_views=1, view_ids=None):
         """batch_depth24 (B,V,P) metres; batch_grid_ft (B,V,P,768); patch_segm (B,V,H,W) or (B*V,1,H,W)
-        dense labels; positions habitat xyz; headings rad."""
+        dense labels; positions habitat xyz; headings rad.  `view_ids` (Pretrain signature, PRE-FF:843,920): view ix looks
+        along heading - view_ids[ix]*pi/6 instead of heading - ix*pi/6 (VLN-FF:550); with is_training=False and no GT point
+        cloud the Pretrain update is otherwise the same state machine (diffed, SURVEY.md 8 note under a23)."""
         P = self.H * self.W
+        if view_ids is not None:
+            num_of_views = len(view_ids)
+        vid = list(range(num_of_views)) if view_ids is None else [int(v) for v in view_ids]
         segm_all = np.asarray(patch_segm).reshape(self.batch_size, num_of_views, P)
         self.last_debug = []
         for b, e in enumerate(self.env):
@@ -157,7 +166,7 @@ class FeatureFieldsOracle:
                 dbg = {}
                 proposal_num = min(len(e.members), self.K)
                 pos, direction, scale = G.unproject_habitat(np.asarray(batch_depth24[b][ix], F32), batch_position[b],
-                                                            ix * (-math.pi / 6) + batch_heading[b], self.H, self.W, self.hfov, self.vfov)
+                                                            vid[ix] * (-math.pi / 6) + batch_heading[b], self.H, self.W, self.hfov, self.vfov)
                 fts16 = np.asarray(batch_grid_ft[b][ix]).astype(np.float16)
                 e.pos = np.concatenate([e.pos, pos], 0)
                 e.dir = np.concatenate([e.dir, direction], 0)

@@ -106,6 +106,38 @@ class _NdArrayEq(np.ndarray):
     __hash__ = None
 
 
+class _ViewIds:
+    """`view_ids` stand-in for the Pretrain class under numpy >= 2: the reference computes
+    `view_ids[ix].cpu().numpy() * (-math.pi / 6) + heading` (PRE-FF:696, 920), a numpy float64 SCALAR, and adds it to float32
+    arrays.  With the numpy 1.x the reference was written for, value-based casting keeps those arrays float32; numpy >= 2
+    (NEP 50) promotes them to float64 and the float32 `nn.Linear`s then reject them.  Handing the index back as a Python int
+    makes the offset a Python float -- 'weak' under NEP 50 -- which reproduces the numpy 1.x arithmetic exactly."""
+
+    class _Item:
+        def __init__(self, v):
+            self.v = int(v)
+
+        def cpu(self):
+            return self
+
+        def numpy(self):
+            return self.v
+
+    def __init__(self, ids):
+        self.ids = [int(i) for i in ids]
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, i):
+        return self._Item(self.ids[i])
+
+    def __eq__(self, other):
+        return False if other is None else NotImplemented
+
+    __hash__ = None
+
+
 class _StoreList(list):
     def __setitem__(self, k, v):
         if isinstance(v, np.ndarray) and not isinstance(v, _NdArrayEq):
@@ -196,6 +228,20 @@ class RefFeatureFields:
         self.F.reset(batch_size)
         self.F.initialize_camera_setting(90.0, 90.0)
         self._wrap_stores()
+
+    @torch.no_grad()
+    def step_pretrain(self, depth_full, depth24, grid_fts, patch_segm, positions, headings, view_ids):
+        """The Pretrain class's per-step pair (PRE-POL:188-189) in inference mode: delete + update with `view_ids`
+        (is_training=False, no GT point cloud).  Same tensor conventions as `step`."""
+        F = self.F
+        B, V = F.batch_size, len(view_ids)
+        vid = _ViewIds(view_ids)
+        F.delete_old_features_from_camera_frustum(depth_full, positions, headings, view_ids=vid)
+        self._wrap_stores()
+        self._segm = patch_segm
+        img = np.zeros((B, V, 8, 8, 3), np.uint8)
+        F.update_feature_fields(depth24, grid_fts, batch_image=img, batch_position=positions, batch_heading=headings,
+                                view_ids=vid, is_training=False)
 
     @torch.no_grad()
     def step(self, depth_full, depth24, grid_fts, patch_segm, positions, headings, num_of_views=1, delete=True):

@@ -91,3 +91,39 @@ class StepOracle:
             self.history[b].append(t + "\n")
         return texts
 
+
+
+class Net3DFFOracle:
+    """`Net_3DFF.forward` up to the memory update (PRE-POL:136-189), inference mode, restated on the pinned pieces:
+    clockwise re-ordering of the 12 panorama sensors (PRE-POL:156-163), views [0,3,6,9] (PRE-POL:165), CLIP on those images
+    (PRE-POL:176), nearest 24x24 depth + preprocess_depth (PRE-POL:179-185), delete + update with `view_ids` (PRE-POL:188-189;
+    the memory update itself is pinned by tests/golden/g4_prepano.npz, generated by the reference's Pretrain class)."""
+    NUM_IMGS = 12
+
+    def __init__(self, sd: Dict[str, torch.Tensor], vit_cfg, batch_size: int, depth_scale=(0.0, 10.0), view_ids=(0, 3, 6, 9)):
+        self.sd, self.vit, self.depth_scale, self.view_ids = sd, vit_cfg, depth_scale, list(view_ids)
+        self.ff = FeatureFieldsOracle(sd, batch_size, num_proposals=4)                    # PRE-FF:45
+
+    @torch.no_grad()
+    def forward(self, observations: Dict[str, np.ndarray], positions, headings, patch_segm):
+        B, V = self.ff.batch_size, len(self.view_ids)
+        depth_batch, rgb_batch = [None] * (self.NUM_IMGS * B), [None] * (self.NUM_IMGS * B)
+        a_count = 0
+        for k, v in observations.items():                                                   # PRE-POL:156-163
+            if "depth" in k:
+                for bi in range(B):
+                    ra = (self.NUM_IMGS - a_count) % self.NUM_IMGS
+                    depth_batch[ra + bi * self.NUM_IMGS] = np.asarray(v[bi])
+                    rgb_batch[ra + bi * self.NUM_IMGS] = np.asarray(observations[k.replace("depth", "rgb")][bi])
+                a_count += 1
+        pick = [bi * self.NUM_IMGS + v for bi in range(B) for v in self.view_ids]            # PRE-POL:173-174
+        depth = np.stack([depth_batch[i] for i in pick]).astype(np.float32)                  # (B*V,H,W,1)
+        rgb = np.stack([rgb_batch[i] for i in pick])
+        px = TR.preprocess_rgb(rgb, self.vit.image)
+        cls, grid = TR.clip_vit_forward(px, self.sd, self.vit.layers, self.vit.heads, self.vit.patch)
+        d24 = G.preprocess_depth(G.downsample_depth_nearest(depth), self.depth_scale).reshape(B, V, -1)       # PRE-POL:181-185
+        origin = G.preprocess_depth(depth, self.depth_scale)[..., 0].reshape(B, V, depth.shape[1], depth.shape[2])
+        self.ff.delete_old_features_from_camera_frustum(origin, positions, headings, view_ids=self.view_ids)
+        self.ff.update_feature_fields(d24, grid.numpy().reshape(B, V, *grid.shape[1:]), patch_segm, positions, headings,
+                                      view_ids=self.view_ids)
+        return dict(rgb_embedding=cls.numpy().reshape(B, V, -1), grid_fts=grid.numpy().reshape(B, V, *grid.shape[1:]), depth24=d24)

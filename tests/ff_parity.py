@@ -13,15 +13,17 @@ def run_case(name, ops, device, on_step=None):
     case = TRAJ_CASES[name]
     g = load(f"g4_{name}.npz")
     sd = synth_state_dict(ff_param_spec(), seed=0)
-    ff = Feature_Fields(case["B"], device=device, state_dict=sd, ops=ops, max_steps=(case["steps"] + 1) * case.get("views", 1))
+    ff = Feature_Fields(case["B"], device=device, state_dict=sd, ops=ops, max_steps=(case["steps"] + 1) * case.get("views", 1),
+                        variant=case.get("variant", "vln"))
     ff.initialize_camera_setting(90.0, 90.0)
-    V = case.get("views", 1)
+    V, vid = case.get("views", 1), case.get("view_ids")           # view_ids = the Pretrain class's keyword (PRE-FF:674,843)
     for t, inp in enumerate(traj_inputs(case)):
         if case.get("pop") and case["pop"][0] == t:
             ff.pop(case["pop"][1])
-        ff.delete_old_features_from_camera_frustum(torch.from_numpy(inp["depth_full"]), inp["positions"], inp["headings"], num_of_views=V)
+        ff.delete_old_features_from_camera_frustum(torch.from_numpy(inp["depth_full"]), inp["positions"], inp["headings"], num_of_views=V,
+                                                   view_ids=vid)
         ff.update_feature_fields(inp["depth24"], inp["grid"], None, inp["positions"], inp["headings"], num_of_views=V,
-                                 patch_segm=inp["patch_segm"])
+                                 patch_segm=inp["patch_segm"], view_ids=vid)
         ev = ff.get_environment_features(inp["positions"], inp["headings"])
         assert ff.batch_size == len(inp["alive"])
         for b in range(ff.batch_size):

@@ -126,17 +126,30 @@ def g4_trajectories():
     """Full Feature_Fields trajectories from the REFERENCE class (VLN-FF), per step and env:
     bookkeeping dicts (exact), instance/zone stores, get_environment_features outputs."""
     sd = synth_state_dict(ff_param_spec(), seed=0)
+    only = os.environ.get("G4_ONLY")
     for name, case in TRAJ_CASES.items():
+        if only and name not in only.split(","):
+            continue
         B, steps = case["B"], case["steps"]
-        ref = rh.RefFeatureFields(B, sd)
+        pre = case.get("variant") == "pretrain"
+        if pre:                                                      # the Pretrain class also owns the renderer's parameters
+            from dynam3d_amd.weights import render_param_spec
+            ref = rh.RefFeatureFields(B, synth_state_dict(ff_param_spec() + render_param_spec(), seed=0), which="pre")
+        else:
+            ref = rh.RefFeatureFields(B, sd)
         out = {"B": np.int64(B), "steps": np.int64(steps)}
         V = case.get("views", 1)
         for t, inp in enumerate(traj_inputs(case)):
             if case.get("pop") and case["pop"][0] == t:
                 ref.F.pop(case["pop"][1])                       # the reference's own pop (VLN-FF:219-243)
                 B = ref.F.batch_size
-            er = ref.step(torch.from_numpy(inp["depth_full"]), inp["depth24"], inp["grid"], torch.from_numpy(inp["patch_segm"]),
-                          inp["positions"], inp["headings"], num_of_views=V)
+            if pre:                                                  # PRE-FF has no get_environment_features: state only
+                ref.step_pretrain(torch.from_numpy(inp["depth_full"]), inp["depth24"], inp["grid"], torch.from_numpy(inp["patch_segm"]),
+                                  inp["positions"], inp["headings"], case["view_ids"])
+                er = None
+            else:
+                er = ref.step(torch.from_numpy(inp["depth_full"]), inp["depth24"], inp["grid"], torch.from_numpy(inp["patch_segm"]),
+                              inp["positions"], inp["headings"], num_of_views=V)
             F = ref.F
             out[f"t{t}_B"] = np.int64(B)
             for b in range(B):
@@ -162,10 +175,11 @@ def g4_trajectories():
                 out[p + "ifts_rowsum"], out[p + "zfts_rowsum"] = iF.astype(np.float64).sum(1), zF.astype(np.float64).sum(1)
                 if t == steps - 1:
                     out[p + "ifts"], out[p + "zfts"] = iF.copy(), zF.copy()
-                for k_, short in [("batch_instance_relative_position", "env_irel"), ("batch_zone_relative_position", "env_zrel")]:
-                    out[p + short] = er[k_][b].numpy().copy()
-                out[p + "env_ifts_head"] = er["batch_instance_fts"][b].numpy()[:, :16].copy()
-                out[p + "env_zfts_head"] = er["batch_zone_fts"][b].numpy()[:, :16].copy()
+                if er is not None:
+                    for k_, short in [("batch_instance_relative_position", "env_irel"), ("batch_zone_relative_position", "env_zrel")]:
+                        out[p + short] = er[k_][b].numpy().copy()
+                    out[p + "env_ifts_head"] = er["batch_instance_fts"][b].numpy()[:, :16].copy()
+                    out[p + "env_zfts_head"] = er["batch_zone_fts"][b].numpy()[:, :16].copy()
             print(name, "step", t, [len(F.global_instance_to_patch_dict[b]) for b in range(B)], flush=True)
         np.savez_compressed(os.path.join(OUT, f"g4_{name}.npz"), **out)
     print("g4 ok")

@@ -20,6 +20,10 @@ TRAJ_CASES = {
     "wall": dict(B=2, steps=5, seed=2, grid_seed=6, stationary=True, wall=2.0, depth_hw=64),
     "pano3": dict(B=2, steps=4, seed=3, grid_seed=7, stationary=False, wall=None, depth_hw=64, views=3),
     "pop": dict(B=3, steps=5, seed=4, grid_seed=8, stationary=False, wall=None, depth_hw=64, pop=(3, 1)),
+    # Pretrain class (PRE-FF) in inference mode: the four 90-degree views of `Net_3DFF.forward` (view_ids 0,3,6,9: view ix
+    # looks along heading - view_ids[ix]*pi/6 in BOTH the cull and the unprojection, PRE-FF:696,920), 4 merge proposals.
+    "prepano": dict(B=2, steps=3, seed=5, grid_seed=9, stationary=False, wall=None, depth_hw=64, views=4, view_ids=[0, 3, 6, 9],
+                    variant="pretrain"),
 }
 
 

@@ -77,6 +77,8 @@ def check_env_against_golden(g, t, b, owner, members, zmembers, zkey, ipos, ifts
         assert rel < 1e-3, rel
         rel = np.linalg.norm(zfts - g[p + "zfts"]) / max(np.linalg.norm(g[p + "zfts"]), 1e-9)
         assert rel < 1e-3, rel
+    if p + "env_irel" not in g.files:                # Pretrain-class goldens: PRE-FF has no get_environment_features
+        return
     assert env["irel"].shape == g[p + "env_irel"].shape
     assert np.all(np.abs(env["irel"] - g[p + "env_irel"]) <= tol(g[p + "env_irel"]))
     assert env["zrel"].shape == g[p + "env_zrel"].shape
@@ -90,13 +92,14 @@ def test_g4_trajectory(name):
     case = TRAJ_CASES[name]
     g = load(f"g4_{name}.npz")
     sd = synth_state_dict(ff_param_spec(), seed=0)
-    orc = FeatureFieldsOracle(sd, case["B"])
-    V = case.get("views", 1)
+    orc = FeatureFieldsOracle(sd, case["B"], num_proposals=4 if case.get("variant") == "pretrain" else 2)
+    V, vid = case.get("views", 1), case.get("view_ids")
     for t, inp in enumerate(traj_inputs(case)):
         if case.get("pop") and case["pop"][0] == t:
             orc.pop(case["pop"][1])
-        orc.delete_old_features_from_camera_frustum(inp["depth_full"], inp["positions"], inp["headings"], num_of_views=V)
-        orc.update_feature_fields(inp["depth24"], inp["grid"], inp["patch_segm"], inp["positions"], inp["headings"], num_of_views=V)
+        orc.delete_old_features_from_camera_frustum(inp["depth_full"], inp["positions"], inp["headings"], num_of_views=V, view_ids=vid)
+        orc.update_feature_fields(inp["depth24"], inp["grid"], inp["patch_segm"], inp["positions"], inp["headings"], num_of_views=V,
+                                  view_ids=vid)
         ev = orc.get_environment_features(inp["positions"], inp["headings"])
         assert len(orc.env) == len(inp["alive"])
         for b, e in enumerate(orc.env):
