@@ -114,6 +114,76 @@ __global__ void k_unproject_append(const float* __restrict__ depth24, const d3d_
     }
 }
 
+// Intrinsics branch of update_feature_fields (PRE-FF:81-94, 905-916): project_depth_to_3d (Open3D create_from_depth_image
+// restated, see oracle/geometry.py::project_depth_to_3d) + nearest (h,w) sampling + world transform + get_heading_angle.
+// One block per (env) view.  Pass 1: image maximum (zero pixels take it, PRE-FF:82) and validity of EVERY pixel (one
+// invalid pixel makes the reference fall back to all-zero points).  Pass 2: the h*w sampled pixels in double.
+__global__ void __launch_bounds__(256)
+k_unproject_pinhole_append(const float* __restrict__ depth, int Hd, int Wd, const d3d_pinhole_unproject* __restrict__ cams,
+                           const int32_t* __restrict__ slot, const int32_t* __restrict__ row_base, int h, int w, int input_width,
+                           float* __restrict__ rows_pos, float* __restrict__ rows_dir, float* __restrict__ rows_scale, int64_t n_cap) {
+    __shared__ float red[256];
+    __shared__ int bad[256];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const d3d_pinhole_unproject cm = cams[e];
+    const float* img = depth + (size_t)e * Hd * Wd;
+    const int n = Hd * Wd;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += 256) mx = fmaxf(mx, img[i]);
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    mx = red[0];
+    auto metres = [&](float raw) -> float {            // uint16 cast, / depth_scale, >= trunc -> 0 (Open3D ConvertDepthToFloatImage)
+        if (raw == 0.0f) raw = mx;
+        const float f = (float)(uint16_t)raw / cm.depth_scale;
+        return f >= cm.depth_trunc ? 0.0f : f;
+    };
+    int nb = 0;
+    for (int i = tid; i < n; i += 256) nb |= !(metres(img[i]) > 0.0f);
+    bad[tid] = nb;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) bad[tid] |= bad[tid + o];
+        __syncthreads();
+    }
+    const bool all_zero = bad[0] != 0;
+    const float sy = (float)Hd / (float)h, sx = (float)Wd / (float)w;      // ATen nearest: float32 scale
+    const int64_t base = (int64_t)slot[e] * n_cap + row_base[e];
+    for (int p = tid; p < h * w; p += 256) {
+        const int r = p / w, c = p % w;
+        int sr = (int)floorf((float)r * sy), sc = (int)floorf((float)c * sx);
+        sr = sr < Hd - 1 ? sr : Hd - 1;
+        sc = sc < Wd - 1 ? sc : Wd - 1;
+        double x = 0.0, y = 0.0, z = 0.0;
+        if (!all_zero) {
+            z = (double)metres(img[(size_t)sr * Wd + sc]);
+            x = ((double)sc - cm.cx) * z / cm.fx;
+            y = ((double)sr - cm.cy) * z / cm.fy;
+        }
+        const float xf = (float)x, yf = (float)y, zf = (float)z;            // points.astype(np.float32)  PRE-FF:907
+        float s = zf * cm.scale_tan;
+        s = s * 2.0f;
+        s = s / (float)input_width;
+        const double wx = (cm.R[0] * (double)xf + cm.R[1] * (double)yf + cm.R[2] * (double)zf) + cm.T[0];
+        const double wy = (cm.R[3] * (double)xf + cm.R[4] * (double)yf + cm.R[5] * (double)zf) + cm.T[1];
+        const double wz = (cm.R[6] * (double)xf + cm.R[7] * (double)yf + cm.R[8] * (double)zf) + cm.T[2];
+        double xy = sqrt(wx * wx + wy * wy);                                  // get_heading_angle  PRE-FF:378-387
+        if (xy < 1e-4) xy = 1e-4;
+        double ang = -asin(wx / xy);
+        if (wy < 0.0) ang = ang - 3.141592653589793;
+        const int64_t row = base + p;
+        rows_pos[row * 3 + 0] = (float)wx;
+        rows_pos[row * 3 + 1] = (float)wy;
+        rows_pos[row * 3 + 2] = (float)wz;
+        rows_dir[row] = (float)ang;
+        rows_scale[row] = s;
+    }
+}
+
 template <bool F16IN>
 __global__ void k_append_fts(const void* __restrict__ grid, const int32_t* __restrict__ slot,
                              const int32_t* __restrict__ row_base, int n_env, int P, uint16_t* __restrict__ rows_fts,
@@ -190,17 +260,40 @@ __device__ __forceinline__ bool frustum_hit(float x, float y, float z, const d3d
     return Z < cd;
 }
 
-__global__ void k_frustum_mask(const float* __restrict__ pts, int64_t n, const float* __restrict__ depth, d3d_pose ps,
+// Intrinsics / extrinsics cull: get_frustum_mask (PRE-FF:98-118).  The two einsums are evaluated as ATen's CPU matmul does
+// for these shapes -- acc = m0*a, then one fused multiply-add per further term, in column order -- which oracle/geometry.py::
+// frustum_mask_pinhole matched bit for bit against the reference on every intermediate value; cm.fx..cy are unused here.
+__device__ __forceinline__ bool frustum_hit(float x, float y, float z, const d3d_pinhole_view& pv, const FrustumCam& cm,
+                                            const float* __restrict__ depth) {
+    const float* V = pv.view;
+    const float X = fmaf(V[3], 1.0f, fmaf(V[2], z, fmaf(V[1], y, V[0] * x)));
+    const float Y = fmaf(V[7], 1.0f, fmaf(V[6], z, fmaf(V[5], y, V[4] * x)));
+    const float Z = fmaf(V[11], 1.0f, fmaf(V[10], z, fmaf(V[9], y, V[8] * x)));
+    const float* K = pv.K;
+    const float uh = fmaf(K[2], Z, fmaf(K[1], Y, K[0] * X));
+    const float vh = fmaf(K[5], Z, fmaf(K[4], Y, K[3] * X));
+    const float zh = fmaf(K[8], Z, fmaf(K[7], Y, K[6] * X));
+    const float uf = uh / zh, vf = vh / zh;
+    const bool in_img = (uf > -1.0f) && (uf < (float)cm.Wd) && (vf > -1.0f) && (vf < (float)cm.Hd);
+    if (!(in_img && Z >= cm.near_ && Z <= cm.far_)) return false;
+    const int u = (int)uf, v = (int)vf;
+    const float cd = depth[(size_t)v * cm.Wd + u] + cm.slack;
+    return Z < cd;
+}
+
+template <class POSE>
+__global__ void k_frustum_mask(const float* __restrict__ pts, int64_t n, const float* __restrict__ depth, POSE ps,
                                FrustumCam cm, uint8_t* __restrict__ mask) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     mask[i] = frustum_hit(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], ps, cm, depth) ? 1 : 0;
 }
 
+template <class POSE>
 __global__ void k_frustum_cull(float* __restrict__ rows_pos, uint16_t* __restrict__ rows_fts, float* __restrict__ rows_dir,
                                float* __restrict__ rows_scale, int64_t n_cap, const int32_t* __restrict__ slot,
                                const int32_t* __restrict__ n_rows, const float* __restrict__ depth,
-                               const d3d_pose* __restrict__ pose, FrustumCam cm, int32_t* __restrict__ hits,
+                               const POSE* __restrict__ pose, FrustumCam cm, int32_t* __restrict__ hits,
                                int32_t* __restrict__ n_hits, int hit_cap, uint8_t* __restrict__ mask) {
     const int e = blockIdx.y;
     const int nr = n_rows[e];
@@ -601,6 +694,19 @@ int32_t d3d_unproject_append(const float* depth24, const d3d_pose* pose, const i
     D3D_LAUNCH_CHECK();
 }
 
+int32_t d3d_unproject_pinhole_append(const float* depth, int32_t Hd, int32_t Wd, const d3d_pinhole_unproject* cams, const int32_t* slot,
+                                     const int32_t* row_base, int32_t n_env, int32_t h, int32_t w, int32_t input_width, float* rows_pos,
+                                     float* rows_dir, float* rows_scale, int64_t n_cap, void* stream) {
+    if (n_env <= 0) return D3D_OK;
+    if (Hd <= 0 || Wd <= 0 || h <= 0 || w <= 0) {
+        d3d_set_error_("d3d_unproject_pinhole_append: empty image or grid");
+        return D3D_EINVAL;
+    }
+    hipLaunchKernelGGL(k_unproject_pinhole_append, dim3(n_env), dim3(256), 0, (hipStream_t)stream, depth, Hd, Wd, cams, slot, row_base, h, w,
+                       input_width, rows_pos, rows_dir, rows_scale, n_cap);
+    D3D_LAUNCH_CHECK();
+}
+
 int32_t d3d_append_fts(const void* grid, int32_t grid_is_f16, const int32_t* slot, const int32_t* row_base, int32_t n_env,
                        int32_t P, uint16_t* rows_fts, int64_t n_cap, void* stream) {
     if (n_env <= 0) return D3D_OK;
@@ -630,8 +736,29 @@ int32_t d3d_frustum_cull(float* rows_pos, uint16_t* rows_fts, float* rows_dir, f
     if (n_env <= 0 || max_rows <= 0) return D3D_OK;
     FrustumCam cm{fx, fy, cx, cy, near_, far_, slack, Hd, Wd};
     dim3 grid((max_rows + 255) / 256, n_env);
-    hipLaunchKernelGGL(k_frustum_cull, grid, dim3(256), 0, (hipStream_t)stream, rows_pos, rows_fts, rows_dir, rows_scale, n_cap,
+    hipLaunchKernelGGL(k_frustum_cull<d3d_pose>, grid, dim3(256), 0, (hipStream_t)stream, rows_pos, rows_fts, rows_dir, rows_scale, n_cap,
                        slot, n_rows, depth, pose, cm, hits, n_hits, hit_cap, mask);
+    D3D_LAUNCH_CHECK();
+}
+
+int32_t d3d_frustum_cull_pinhole(float* rows_pos, uint16_t* rows_fts, float* rows_dir, float* rows_scale, int64_t n_cap,
+                                 const int32_t* slot, const int32_t* n_rows, int32_t n_env, int32_t max_rows, const float* depth,
+                                 int32_t Hd, int32_t Wd, const d3d_pinhole_view* views, float near_, float far_, float slack,
+                                 int32_t* hits, int32_t* n_hits, int32_t hit_cap, uint8_t* mask, void* stream) {
+    if (n_env <= 0 || max_rows <= 0) return D3D_OK;
+    FrustumCam cm{0.f, 0.f, 0.f, 0.f, near_, far_, slack, Hd, Wd};
+    dim3 grid((max_rows + 255) / 256, n_env);
+    hipLaunchKernelGGL(k_frustum_cull<d3d_pinhole_view>, grid, dim3(256), 0, (hipStream_t)stream, rows_pos, rows_fts, rows_dir,
+                       rows_scale, n_cap, slot, n_rows, depth, views, cm, hits, n_hits, hit_cap, mask);
+    D3D_LAUNCH_CHECK();
+}
+
+int32_t d3d_frustum_mask_pinhole(const float* points, int64_t n, const float* depth, int32_t Hd, int32_t Wd,
+                                 const d3d_pinhole_view* view_h, float near_, float far_, float slack, uint8_t* mask, void* stream) {
+    if (n <= 0) return D3D_OK;
+    FrustumCam cm{0.f, 0.f, 0.f, 0.f, near_, far_, slack, Hd, Wd};
+    hipLaunchKernelGGL(k_frustum_mask<d3d_pinhole_view>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, points, n,
+                       depth, *view_h, cm, mask);
     D3D_LAUNCH_CHECK();
 }
 
@@ -639,7 +766,7 @@ int32_t d3d_frustum_mask(const float* points, int64_t n, const float* depth, int
                          float fx, float fy, float cx, float cy, float near_, float far_, float slack, uint8_t* mask, void* stream) {
     if (n <= 0) return D3D_OK;
     FrustumCam cm{fx, fy, cx, cy, near_, far_, slack, Hd, Wd};
-    hipLaunchKernelGGL(k_frustum_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, points, n, depth,
+    hipLaunchKernelGGL(k_frustum_mask<d3d_pose>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, points, n, depth,
                        *pose_h, cm, mask);
     D3D_LAUNCH_CHECK();
 }

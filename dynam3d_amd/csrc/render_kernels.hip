@@ -40,6 +40,27 @@ __global__ void k_rays_habitat(const double* __restrict__ rel_y, const float* __
     o[2] = (float)(z + ps[2]);
 }
 
+// get_rays (PRE-FF:390-405) + world transform of the intrinsics mode (PRE-FF:534): Open3D unprojects N constant-depth images
+// in double, then ray = R @ rel + T in double, rounded to float32 once.  z (N) f64 = float32(near + spacing*(i+1)) widened;
+// cam (n_env,16) f64 = fx, fy, cx, cy, R[9] row-major, T[3].  Ray r = pixel (row r / W, col r % W).
+__global__ void k_rays_pinhole(const double* __restrict__ zs, const double* __restrict__ cam, int R, int N, int W,
+                               float* __restrict__ ray) {
+    const int e = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)R * N) return;
+    const int r = (int)(i / N), n = (int)(i % N);
+    const double* c = cam + e * 16;
+    const double z = zs[n];
+    const double x = ((double)(r % W) - c[2]) * z / c[0];
+    const double y = ((double)(r / W) - c[3]) * z / c[1];
+    const double* Rm = c + 4;
+    const double* T = c + 13;
+    float* o = ray + ((int64_t)e * R * N + i) * 3;
+    o[0] = (float)(((Rm[0] * x + Rm[1] * y) + Rm[2] * z) + T[0]);
+    o[1] = (float)(((Rm[3] * x + Rm[4] * y) + Rm[5] * z) + T[1]);
+    o[2] = (float)(((Rm[6] * x + Rm[7] * y) + Rm[8] * z) + T[2]);
+}
+
 // one wave per ray.  d2/idx: (n_rays*N, KK).  Importance = 1/sum_j min(sqrt(d2_j) >= radius ? radius : sqrt(d2_j)).
 // top-n_imp by (importance desc, sample index asc).  Writes topk (n_imp), masked neighbour ids of the chosen samples
 // (n_imp, KK) and the number of samples that have at least one neighbour inside the radius.
@@ -228,6 +249,15 @@ int32_t d3d_rays_habitat(const double* rel_y, const float* tan_xy, const float* 
     if (n_env <= 0) return D3D_OK;
     dim3 grid((unsigned)(((int64_t)R * N + 255) / 256), n_env);
     hipLaunchKernelGGL(k_rays_habitat, grid, dim3(256), 0, (hipStream_t)stream, rel_y, tan_xy, tan_z, pose64, R, N, ray_xyz);
+    D3D_LAUNCH_CHECK();
+}
+
+int32_t d3d_rays_pinhole(const double* z, const double* cam16, int32_t n_env, int32_t view_h, int32_t view_w, int32_t N, float* ray_xyz,
+                         void* stream) {
+    if (n_env <= 0) return D3D_OK;
+    const int R = view_h * view_w;
+    dim3 grid((unsigned)(((int64_t)R * N + 255) / 256), n_env);
+    hipLaunchKernelGGL(k_rays_pinhole, grid, dim3(256), 0, (hipStream_t)stream, z, cam16, R, N, view_w, ray_xyz);
     D3D_LAUNCH_CHECK();
 }
 

@@ -25,7 +25,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .ops import FTS, CameraTables, Pools, make_pose
+from .ops import pinhole_unproject_rows, pinhole_views, FTS, CameraTables, Pools, make_pose
 from ._ffstate import FFState
 from .ff_dense import FFDense
 
@@ -36,7 +36,25 @@ def _args_namespace():
     # VLN-FF:22-46 defaults (fts_dim is declared float there; kept numeric-compatible)
     return SimpleNamespace(input_hfov=90.0, input_vfov=90.0, input_height=24, input_width=24, fts_dim=768,
                            zone_x_length=2.0, zone_y_length=2.0, zone_z_length=2.0, deleted_frustum_distance=3.0,
-                           num_proposal_instances=2)
+                           num_proposal_instances=2,
+                           # novel-view rays of the Pretrain class (PRE-FF:47-74); used by the renderer and, in the intrinsics
+                           # mode, for the patch scale (PRE-FF:849-856, 909)
+                           near=0.0, far=10.0, view_height=12, view_width=12, N_samples=501)
+
+
+def _host(x):
+    """tensor / array / nested list -> numpy on the host (camera matrices are a few numbers per view)."""
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def _ray0_tan(fx_view: float, view_width: int, near: float, far: float, n_samples: int) -> float:
+    """|tan(rel_direction[0][-1])| of `get_rays(init_camera_intrinsic)` (PRE-FF:390-405, 909): ray 0 = pixel (0,0), last depth
+    sample, principal point view_width/2; Open3D evaluates x = (0 - cx) * z / fx in double on the float32 depth value."""
+    z = float(np.float32(near + (far - near) / n_samples * n_samples))
+    x = (0.0 - view_width / 2) * z / fx_view
+    return math.fabs(math.tan(-math.atan(x / z)))
 
 
 class Feature_Fields:
@@ -91,8 +109,11 @@ class Feature_Fields:
                              batch_trans=None, visualization=False, debug=False, **render_kw):
         """Novel-view 12x12 feature map rendered from the stored patches (Pretrain `Feature_Fields` surface).
         Returns (features (B,12,12,768), positions (B,12,12,3), gt_labels=[]) like the reference (habitat mode)."""
-        if batch_rot is not None or batch_camera_intrinsic is not None:
-            raise NotImplementedError("intrinsics/extrinsics mode: SURVEY.md 8f-2")
+        pin = {}
+        if batch_rot is not None:                                       # intrinsics mode (PRE-FF:505-515, 532-536)
+            if getattr(self, "view_intrinsic", None) is None:
+                raise RuntimeError("intrinsics mode renders with the rays of the last update_feature_fields(batch_camera_intrinsic=...)")
+            pin = dict(batch_rot=[_host(r) for r in batch_rot], batch_trans=[_host(t) for t in batch_trans], view_intrinsic=self.view_intrinsic)
         if not getattr(self, "_render_sd", None):
             raise RuntimeError("no renderer weights loaded (nerf_encoder/nerf_decoder/... keys of the Pretrain checkpoint)")
         if self._renderer is None:
@@ -100,7 +121,7 @@ class Feature_Fields:
             self._renderer = FieldRenderer(self._render_sd, self.device, **render_kw)
         st = self.state
         n_rows = [st.count(e, st.ROWS) for e in range(self.batch_size)]
-        out = self._renderer.render(self.pools, self.slots, n_rows, batch_position, batch_heading, self.ops, debug=debug)
+        out = self._renderer.render(self.pools, self.slots, n_rows, batch_position, batch_heading, self.ops, debug=debug, **pin)
         return (out[0], out[1], []) + tuple(out[2:])
 
     def eval(self):
@@ -167,6 +188,21 @@ class Feature_Fields:
             view_ids = view_ids.cpu().numpy()
         return [int(v) for v in np.asarray(view_ids).reshape(-1)]
 
+    def _stack_views(self, batch_depth) -> torch.Tensor:
+        """list over envs of (V,H,W) images (or one (B,V,H,W) array) -> (B,V,H,W) float32 on the device; the batched kernels need
+        the same number and size of views for every environment of the batch."""
+        if isinstance(batch_depth, (list, tuple)):
+            items = [torch.as_tensor(np.asarray(_host(d))) for d in batch_depth]
+            if len({tuple(t.shape) for t in items}) != 1:
+                raise ValueError("intrinsics mode: every environment of the batch must bring the same (V,H,W) depth stack")
+            batch_depth = torch.stack(items)
+        d = self._dev(batch_depth)
+        if d.dim() == 5 and d.shape[-1] == 1:
+            d = d[..., 0]
+        if d.dim() != 4:
+            raise ValueError("depth stack must be (B,V,H,W)")
+        return d.contiguous()
+
     def _poses(self, positions, headings, envs, view_offset=0.0) -> torch.Tensor:
         return self._f32(np.stack([make_pose(positions[e], view_offset + float(headings[e])) for e in envs]))
 
@@ -194,8 +230,10 @@ class Feature_Fields:
                                                 batch_camera_intrinsic=None, batch_extrinsic=None, num_of_views=1, view_ids=None):
         """`view_ids` is the Pretrain variant's keyword (PRE-FF:674): V = len(view_ids) and view ix is culled along
         heading - view_ids[ix]*pi/6 (PRE-FF:696); `num_of_views` is the VLN variant's (no per-view offset, VLN-FF:347)."""
-        if batch_extrinsic is not None:
-            raise NotImplementedError("intrinsics/extrinsics (non-Habitat datasets) path: SURVEY.md 8f-2")
+        pinhole = batch_extrinsic is not None
+        if pinhole:                                                     # PRE-FF:680-681: every view of the env, in order
+            batch_depth = self._stack_views(batch_depth)
+            num_of_views, view_ids = batch_depth.shape[1], None
         view_ids = self._view_ids(view_ids)
         if view_ids is not None:
             num_of_views = len(view_ids)
@@ -210,14 +248,20 @@ class Feature_Fields:
             if not envs:
                 continue
             n_rows = [st.count(e, st.ROWS) for e in envs]
-            pose = self._poses(batch_position, batch_heading, envs,        # VLN: no per-view offset (VLN-FF:347)
-                               view_offset=0.0 if view_ids is None else view_ids[ix] * (-math.pi / 6))
             slot = self._i32([self.slots[e] for e in envs])
             hits = torch.empty((len(envs), max(n_rows)), dtype=torch.int32, device=self.device)
             n_hits = torch.zeros((len(envs),), dtype=torch.int32, device=self.device)
             d_ix = depth[envs, ix].contiguous() if len(envs) != B else depth[:, ix].contiguous()
-            self.ops.frustum_cull(pools, slot, self._i32(n_rows), max(n_rows), d_ix, pose, intr, 0.0,
-                                  float(a.deleted_frustum_distance), 0.1, hits, n_hits)
+            if pinhole:                                                 # get_frustum_mask (PRE-FF:98-118, 693)
+                views = torch.from_numpy(pinhole_views([_host(batch_camera_intrinsic[e][ix]) for e in envs],
+                                                       [_host(batch_extrinsic[e][ix]) for e in envs])).to(self.device)
+                self.ops.frustum_cull_pinhole(pools, slot, self._i32(n_rows), max(n_rows), d_ix, views, 0.0,
+                                              float(a.deleted_frustum_distance), 0.1, hits, n_hits)
+            else:
+                pose = self._poses(batch_position, batch_heading, envs,    # VLN: no per-view offset (VLN-FF:347)
+                                   view_offset=0.0 if view_ids is None else view_ids[ix] * (-math.pi / 6))
+                self.ops.frustum_cull(pools, slot, self._i32(n_rows), max(n_rows), d_ix, pose, intr, 0.0,
+                                      float(a.deleted_frustum_distance), 0.1, hits, n_hits)
             n_hits_h = n_hits.cpu().numpy()                                  # sync #1: a few ints
             mx = int(n_hits_h.max())
             if mx == 0:
@@ -253,10 +297,18 @@ class Feature_Fields:
                               is_training=False):
         """`num_of_views` (VLN-FF:493: view ix at heading - ix*pi/6) or `view_ids` (PRE-FF:843,920: view ix at
         heading - view_ids[ix]*pi/6, e.g. [0,3,6,9] = the four 90-degree views of `Net_3DFF.forward`, PRE-POL:160)."""
-        if batch_camera_intrinsic is not None:
-            raise NotImplementedError("Open3D / intrinsics path (non-Habitat datasets): SURVEY.md 8f-2")
         if is_training:
             raise NotImplementedError("pre-training losses: SURVEY.md 8f-1")
+        pinhole = batch_camera_intrinsic is not None
+        a = self.args
+        if pinhole:
+            # "Most 3D datasets" (PRE-FF:849-856, 886-916): raw depth images + pinhole intrinsics + camera->world (R, T) per view.
+            depth_raw = self._stack_views(batch_depth)                       # (B,V,Hd,Wd) raw sensor units
+            num_of_views, view_ids = depth_raw.shape[1], None
+            K0 = _host(batch_camera_intrinsic[0][0])
+            self.view_intrinsic = (float(K0[0][0]) * (a.view_width / depth_raw.shape[-1]),    # init_camera_intrinsic (PRE-FF:851-855)
+                                   float(K0[1][1]) * (a.view_height / depth_raw.shape[-2]))
+            scale_tan = _ray0_tan(self.view_intrinsic[0], a.view_width, a.near, a.far, a.N_samples)
         view_ids = self._view_ids(view_ids)
         if view_ids is not None:
             num_of_views = len(view_ids)
@@ -270,7 +322,7 @@ class Feature_Fields:
         if isinstance(patch_segm, torch.Tensor):
             patch_segm = patch_segm.cpu().numpy()
         segm_all = np.asarray(patch_segm).reshape(B, V, P).astype(np.int32)
-        depth24 = self._dev(batch_depth).view(B, V, P)
+        depth24 = None if pinhole else self._dev(batch_depth).view(B, V, P)
         if isinstance(batch_grid_ft, (list, tuple)):
             batch_grid_ft = np.stack([np.asarray(g) for g in batch_grid_ft])
         grid = batch_grid_ft if isinstance(batch_grid_ft, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(batch_grid_ft))
@@ -289,9 +341,15 @@ class Feature_Fields:
             rb, k0, has_tree = zip(*[st.begin_view(e) for e in envs])
             k0 = [k if t else 0 for k, t in zip(k0, has_tree)]
             row_base = self._i32(rb)
-            pose = self._poses(batch_position, batch_heading, envs,                                     # VLN-FF:550 / PRE-FF:920
-                               view_offset=(ix if view_ids is None else view_ids[ix]) * (-math.pi / 6))
-            ops.unproject_append(depth24[:, ix].contiguous(), pose, slot, row_base, cam, pools)
+            if pinhole:                                                                                   # PRE-FF:905-916
+                cams = pinhole_unproject_rows([_host(batch_camera_intrinsic[e][ix]) for e in envs], [_host(batch_rot[e][ix]) for e in envs],
+                                              [_host(batch_trans[e][ix]) for e in envs], scale_tan, depth_scale, depth_trunc)
+                ops.unproject_pinhole_append(depth_raw[:, ix].contiguous(), torch.from_numpy(cams).to(self.device), slot, row_base,
+                                             a.input_height, a.input_width, a.input_width, pools)
+            else:
+                pose = self._poses(batch_position, batch_heading, envs,                                 # VLN-FF:550 / PRE-FF:920
+                                   view_offset=(ix if view_ids is None else view_ids[ix]) * (-math.pi / 6))
+                ops.unproject_append(depth24[:, ix].contiguous(), pose, slot, row_base, cam, pools)
             ops.append_fts(grid[:, ix].contiguous(), slot, row_base, pools)
 
             # ---- 2D instances of this frame: groups padded to n_max per env -------------------------

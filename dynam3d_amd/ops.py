@@ -28,6 +28,30 @@ def make_pose(position_habitat: Sequence[float], heading: float) -> np.ndarray:
     return p
 
 
+def pinhole_views(intrinsics, extrinsics) -> np.ndarray:
+    """d3d_pinhole_view rows: rows 0..2 of each 4x4 world->camera matrix, then K[:3,:3], float32 (PRE-FF:101-108)."""
+    out = np.zeros((len(intrinsics), 21), np.float32)
+    for i, (K, V) in enumerate(zip(intrinsics, extrinsics)):
+        out[i, :12] = np.asarray(V, np.float32)[:3, :4].reshape(-1)
+        out[i, 12:] = np.asarray(K, np.float32)[:3, :3].reshape(-1)
+    return out
+
+
+def pinhole_unproject_rows(intrinsics, rots, trans, scale_tan: float, depth_scale: float, depth_trunc: float) -> np.ndarray:
+    """d3d_pinhole_unproject rows as 18 float64 words: fx, fy, cx, cy, R[9], T[3], then (scale_tan, depth_scale) and
+    (depth_trunc, pad) packed as float32 pairs."""
+    out = np.zeros((len(intrinsics), 18), np.float64)
+    tail = np.zeros((len(intrinsics), 4), np.float32)
+    for i, (K, R, T) in enumerate(zip(intrinsics, rots, trans)):
+        K = np.asarray(K, np.float64)
+        out[i, :4] = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+        out[i, 4:13] = np.asarray(R, np.float64).reshape(-1)
+        out[i, 13:16] = np.asarray(T, np.float64).reshape(-1)
+        tail[i] = scale_tan, depth_scale, depth_trunc, 0.0
+    out[:, 16:18] = tail.view(np.float64)
+    return out
+
+
 @dataclass
 class CameraTables:
     """Per-patch tangent tables (VLN-FF:283-287): python-float arithmetic rounded to float32 exactly as
@@ -162,6 +186,30 @@ class HipOps:
         self._ck(self.lib.d3d_frustum_mask(_ptr(points), N, _ptr(depth), Hd, Wd, ph.ctypes.data_as(C.c_void_p), fx, fy, cx, cy,
                                            near, far, slack, _ptr(mask), self._stream()))
         return mask
+
+    # -- intrinsics / extrinsics path --------------------------------------------------
+    def frustum_cull_pinhole(self, pools: Pools, slot, n_rows, max_rows, depth, views, near, far, slack, hits, n_hits, mask=None):
+        """views: (n_env, 21) float32 device tensor = d3d_pinhole_view rows (see `pinhole_views`)."""
+        n, Hd, Wd = depth.shape
+        self._ck(self.lib.d3d_frustum_cull_pinhole(_ptr(pools.rows_pos), _ptr(pools.rows_fts), _ptr(pools.rows_dir), _ptr(pools.rows_scale),
+                                                   pools.n_cap, _ptr(slot), _ptr(n_rows), n, max_rows, _ptr(depth), Hd, Wd, _ptr(views),
+                                                   near, far, slack, _ptr(hits), _ptr(n_hits), hits.shape[1], _ptr(mask), self._stream()))
+
+    def frustum_mask_pinhole(self, points, depth, view_host: np.ndarray, near, far, slack):
+        N = points.shape[0]
+        Hd, Wd = depth.shape
+        mask = torch.empty(N, dtype=torch.uint8, device=points.device)
+        vh = np.ascontiguousarray(view_host, np.float32)
+        self._ck(self.lib.d3d_frustum_mask_pinhole(_ptr(points), N, _ptr(depth), Hd, Wd, vh.ctypes.data_as(C.c_void_p), near, far, slack,
+                                                   _ptr(mask), self._stream()))
+        return mask
+
+    def unproject_pinhole_append(self, depth, cams, slot, row_base, h, w, input_width, pools: Pools):
+        """depth (n_env,Hd,Wd) f32 raw sensor units; cams: (n_env, 18) float64 device tensor = d3d_pinhole_unproject rows."""
+        n, Hd, Wd = depth.shape
+        self._ck(self.lib.d3d_unproject_pinhole_append(_ptr(depth), Hd, Wd, _ptr(cams), _ptr(slot), _ptr(row_base), n, h, w, input_width,
+                                                       _ptr(pools.rows_pos), _ptr(pools.rows_dir), _ptr(pools.rows_scale), pools.n_cap,
+                                                       self._stream()))
 
     # -- a8 -------------------------------------------------------------------------------------
     def knn(self, points, point_stride, n_points, queries, query_stride, n_queries, k, n_batch, max_queries, k_max):

@@ -22,6 +22,7 @@ from .ops import FTS, Pools
 from .tcnn import Network
 
 _lib.register("d3d_rays_habitat", [vp, vp, vp, vp, i32, i32, i32, vp, vp])
+_lib.register("d3d_rays_pinhole", [vp, vp, i32, i32, i32, i32, vp, vp])
 _lib.register("d3d_ray_topk", [vp, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp])
 _lib.register("d3d_render_embed", [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, f32, vp, vp, vp, vp])
 _lib.register("d3d_composite", [vp, i64, vp, i64, vp, vp, i32, i32, i32, vp, vp, vp])
@@ -66,15 +67,49 @@ class FieldRenderer:
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     @torch.no_grad()
-    def render(self, pools: Pools, slots: Sequence[int], n_rows: Sequence[int], batch_position, batch_heading, ops, debug=False):
-        """-> (features (B,H,W,768) f32 unit-norm, positions (B,H,W,3), depth (B,H,W)[, debug dict])."""
+    def _pinhole_tables(self, fx: float, fy: float):
+        """get_rays (PRE-FF:390-405) for the view-sized intrinsics: depth samples near + spacing*(i+1) stored as float32 images,
+        unprojected by Open3D in double; rel_direction = -arctan(x/z) of the last sample; rel_dist = z (later cast to fp16)."""
+        key = (float(fx), float(fy))
+        if getattr(self, "_pin_key", None) != key:
+            spacing = (self.far - self.near) / self.N
+            z = np.array([np.float32(self.near + spacing * (i + 1)) for i in range(self.N)], np.float64)
+            cx = self.W / 2
+            x_last = (np.tile(np.arange(self.W, dtype=np.float64), self.H) - cx) * z[-1] / fx
+            t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(self.dev)
+            self._pin = dict(z=t(z, np.float64), rel_dir=t(-np.arctan(x_last / z[-1]), np.float32),
+                             rel_dist16=t(z.astype(np.float16).astype(np.float32), np.float32))
+            self._pin_key = key
+        return self._pin
+
+    def render(self, pools: Pools, slots: Sequence[int], n_rows: Sequence[int], batch_position, batch_heading, ops, debug=False,
+               batch_rot=None, batch_trans=None, view_intrinsic=None):
+        """-> (features (B,H,W,768) f32 unit-norm, positions (B,H,W,3), depth (B,H,W)[, debug dict]).
+        Habitat mode: `batch_position` / `batch_heading`.  Intrinsics mode (PRE-FF:505-515, 532-536): camera->world `batch_rot` /
+        `batch_trans` per env and the view-sized (fx, fy) of the last update."""
         B, R, N, S, K = len(slots), self.R, self.N, self.n_imp, self.k
         dev, lib, st = self.dev, self.lib, self._stream
-        pose64 = np.array([[p[0], -p[2], p[1], math.cos(h), math.sin(h)] for p, h in zip(batch_position, batch_heading)], np.float64)
-        pose3 = np.array([[np.float32(math.cos(-h)), np.float32(math.sin(-h)), np.float32(h)] for h in batch_heading], np.float32)
         i32t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(dev)
         ray = torch.empty((B, R * N, 3), dtype=torch.float32, device=dev)
-        _lib.check(lib.d3d_rays_habitat(_p(self.rel_y64), _p(self.tan_xy), _p(self.tan_z), _p(torch.from_numpy(pose64).to(dev)), B, R, N, _p(ray), st()))
+        if batch_rot is not None:
+            fx, fy = view_intrinsic
+            tab = self._pinhole_tables(fx, fy)
+            cam16 = np.zeros((B, 16), np.float64)
+            heads = []
+            for b in range(B):
+                Rm, T = np.asarray(batch_rot[b], np.float64).reshape(3, 3), np.asarray(batch_trans[b], np.float64).reshape(3)
+                cam16[b] = [fx, fy, self.W / 2, self.H / 2, *Rm.reshape(-1), *T]
+                fwd = Rm @ np.array([0.0, 0.0, 1.0]) + T                   # PRE-FF:512-515: heading of the WORLD point R@[0,0,1]+T
+                xy = max(math.sqrt(fwd[0] ** 2 + fwd[1] ** 2), 1e-4)
+                h = -math.asin(fwd[0] / xy) - (math.pi if fwd[1] < 0 else 0.0)
+                heads.append(float(np.float32(h)))                         # torch.tensor(..., dtype=float32)
+            _lib.check(lib.d3d_rays_pinhole(_p(tab["z"]), _p(torch.from_numpy(cam16).to(dev)), B, self.H, self.W, N, _p(ray), st()))
+            rel_dir, rel_dist16, batch_heading = tab["rel_dir"], tab["rel_dist16"], heads
+        else:
+            pose64 = np.array([[p[0], -p[2], p[1], math.cos(h), math.sin(h)] for p, h in zip(batch_position, batch_heading)], np.float64)
+            _lib.check(lib.d3d_rays_habitat(_p(self.rel_y64), _p(self.tan_xy), _p(self.tan_z), _p(torch.from_numpy(pose64).to(dev)), B, R, N, _p(ray), st()))
+            rel_dir, rel_dist16 = self.rel_dir, self.rel_dist16
+        pose3 = np.array([[np.float32(math.cos(-h)), np.float32(math.sin(-h)), np.float32(h)] for h in batch_heading], np.float32)
         ident = all(s == i for i, s in enumerate(slots))
         pts = pools.rows_pos if ident else pools.rows_pos.index_select(0, i32t(slots).long()).contiguous()
         d2, idx = ops.knn(pts, pools.n_cap * 3, i32t(n_rows), ray, R * N * 3, i32t([R * N] * B), i32t([K] * B), B, R * N, K)   # PRE-FF:540
@@ -89,7 +124,7 @@ class FieldRenderer:
         sample_xyz = torch.empty((n_rays, S, 3), dtype=torch.float32, device=dev)
         geom6 = torch.empty((n_rays * S * K, 6), dtype=torch.float32, device=dev) if debug else None
         _lib.check(lib.d3d_render_embed(_p(pools.rows_pos), _p(pools.rows_dir), _p(pools.rows_scale), _p(pools.rows_fts), pools.n_cap, _p(ray_slot),
-                                        _p(ray_env), _p(ray), _p(topk), _p(sidx), _p(torch.from_numpy(pose3).to(dev)), _p(self.rel_dir), n_rays, R, N, S, K,
+                                        _p(ray_env), _p(ray), _p(topk), _p(sidx), _p(torch.from_numpy(pose3).to(dev)), _p(rel_dir), n_rays, R, N, S, K,
                                         self.far, _p(self.w6), _p(self.b6), _p(self.ln6[0]), _p(self.ln6[1]), 1e-12, _p(s16), _p(geom6), _p(sample_xyz), st()))
         x = self.hd.gemm(s16, self.agg_w, self.agg_b, None, "bias")                              # PRE-FF:483 Linear(3072,768)
         x = self.hd.layer_norm(x, self.agg_ln[0], self.agg_ln[1], 1e-12)
@@ -99,7 +134,7 @@ class FieldRenderer:
         out = self.decoder(y).contiguous()                                                       # (M,768) fp16   PRE-FF:488
         fmap = torch.empty((n_rays, FTS), dtype=torch.float32, device=dev)
         depth = torch.empty((n_rays,), dtype=torch.float32, device=dev)
-        _lib.check(lib.d3d_composite(_p(out), out.stride(0), _p(dens), dens.stride(0), _p(self.rel_dist16), _p(topk), n_rays, N, S, _p(fmap), _p(depth), st()))
+        _lib.check(lib.d3d_composite(_p(out), out.stride(0), _p(dens), dens.stride(0), _p(rel_dist16), _p(topk), n_rays, N, S, _p(fmap), _p(depth), st()))
         res = (fmap.view(B, self.H, self.W, FTS), sample_xyz[:, 0].reshape(B, self.H, self.W, 3), depth.view(B, self.H, self.W))
         if debug:
             return res + (dict(topk=topk.view(B, R, S), sidx=sidx.view(B, R, S, K), n_ranked=n_ranked.view(B, R), geom6=geom6.view(B, R, S, K, 6),

@@ -96,6 +96,44 @@ int32_t d3d_frustum_cull(float* rows_pos_d, uint16_t* rows_fts_d, float* rows_di
                          float fx, float fy, float cx, float cy, float near_, float far_, float slack,
                          int32_t* hits_d, int32_t* n_hits_d, int32_t hit_cap, uint8_t* mask_d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Intrinsics / extrinsics path (posed RGB-D datasets with a pinhole camera).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct d3d_pinhole_view {
+    float view[12]; /* rows 0..2 of the 4x4 world->camera matrix `batch_extrinsic[b][ix]` (PRE-FF:693) */
+    float K[9];     /* `batch_camera_intrinsic[b][ix][:3,:3]` row-major (PRE-FF:101) */
+} d3d_pinhole_view;
+
+/* get_frustum_mask + depth test + tomb-stoning (PRE-FF:98-118, 693-712): as d3d_frustum_cull with the camera given by a
+ * view matrix and an intrinsics matrix per env.  einsum accumulation order = ATen's CPU matmul (acc = m0*a, then fmaf per
+ * term), bit-exact against tests/golden/g2b_frustum_pinhole.npz. */
+int32_t d3d_frustum_cull_pinhole(float* rows_pos_d, uint16_t* rows_fts_d, float* rows_dir_d, float* rows_scale_d,
+                                 int64_t n_cap, const int32_t* slot_d, const int32_t* n_rows_d, int32_t n_env,
+                                 int32_t max_rows, const float* depth_d, int32_t Hd, int32_t Wd,
+                                 const d3d_pinhole_view* views_d, float near_, float far_, float slack, int32_t* hits_d,
+                                 int32_t* n_hits_d, int32_t hit_cap, uint8_t* mask_d, void* stream);
+int32_t d3d_frustum_mask_pinhole(const float* points_d, int64_t n, const float* depth_d, int32_t Hd, int32_t Wd,
+                                 const d3d_pinhole_view* view_host, float near_, float far_, float slack, uint8_t* mask_d,
+                                 void* stream);
+
+typedef struct d3d_pinhole_unproject {
+    double fx, fy, cx, cy; /* batch_camera_intrinsic[b][ix] (PRE-FF:84) */
+    double R[9], T[3];     /* batch_rot[b][ix], batch_trans[b][ix]: camera -> world (PRE-FF:910-912) */
+    float scale_tan;       /* |tan(rel_direction[0][-1])| of the view-sized rays (PRE-FF:849-856, 909) */
+    float depth_scale;     /* Open3D depth_scale (raw units per metre) and depth_trunc (metres) */
+    float depth_trunc;
+    float pad_;
+} d3d_pinhole_unproject;
+
+/* project_depth_to_3d + world transform + get_heading_angle + append (PRE-FF:81-94, 905-916; the Open3D call restated
+ * from its published algorithm -- PARITY UNPINNED, see oracle/geometry.py::project_depth_to_3d).  depth_d (n_env,Hd,Wd)
+ * f32 RAW sensor units (zero pixels take the image maximum; values are cast to uint16 like the reference does); writes
+ * h*w rows at row_base_d[e] of slot slot_d[e].  If any pixel of image e is invalid, all its points are zero (PRE-FF:90). */
+int32_t d3d_unproject_pinhole_append(const float* depth_d, int32_t Hd, int32_t Wd, const d3d_pinhole_unproject* cams_d,
+                                     const int32_t* slot_d, const int32_t* row_base_d, int32_t n_env, int32_t h,
+                                     int32_t w, int32_t input_width, float* rows_pos_d, float* rows_dir_d,
+                                     float* rows_scale_d, int64_t n_cap, void* stream);
+
 /* stand-alone mask (no mutation) for one point set -- used by tests and by torch-free callers. */
 int32_t d3d_frustum_mask(const float* points_d, int64_t n, const float* depth_d, int32_t Hd, int32_t Wd,
                          const d3d_pose* pose_h, float fx, float fy, float cx, float cy, float near_, float far_,
@@ -246,6 +284,10 @@ int32_t d3d_resize_normalize(const uint8_t* rgb_d, float* out_d, int32_t B, int3
  * rel_y (N) f64 = linspace(near,far,N); tan_xy/tan_z (R) f32; pose64 (n_env,5) = cx,cy,cz,cos h,sin h -> ray (n_env,R,N,3) */
 int32_t d3d_rays_habitat(const double* rel_y_d, const float* tan_xy_d, const float* tan_z_d, const double* pose64_d,
                          int32_t n_env, int32_t R, int32_t N, float* ray_xyz_d, void* stream);
+/* a20 get_rays + world transform, intrinsics mode (PRE-FF:390-405, 534): z (N) f64 = float32(near + spacing*(i+1)) widened;
+ * cam16 (n_env,16) f64 = fx, fy, cx, cy, R[9] row-major, T[3] -> ray (n_env, view_h*view_w, N, 3) f32 */
+int32_t d3d_rays_pinhole(const double* z_d, const double* cam16_d, int32_t n_env, int32_t view_h, int32_t view_w, int32_t N,
+                         float* ray_xyz_d, void* stream);
 /* a21 importance sampling (PRE-FF:543-556): from the k-NN table (n_rays*N, k): dist = sqrt(d2), >= radius -> none;
  * importance 1/sum(dist); top n_imp per ray by (importance desc, sample index asc) -> topk (n_rays,n_imp), neighbour
  * ids of the chosen samples sidx (n_rays,n_imp,k) (-1 = none), n_ranked (n_rays) samples with a neighbour in range */

@@ -110,20 +110,27 @@ class FeatureFieldsOracle:
         return G.mean_rows_f64(x)
 
     # ---- a4 + cascade: delete_old_features_from_camera_frustum (VLN-FF:329-396) ---------------
-    def delete_old_features_from_camera_frustum(self, batch_depth, batch_position, batch_heading, num_of_views=1, view_ids=None):
+    def delete_old_features_from_camera_frustum(self, batch_depth, batch_position=None, batch_heading=None, num_of_views=1, view_ids=None,
+                                                batch_camera_intrinsic=None, batch_extrinsic=None):
         """batch_depth (B,V,Hd,Wd) metres (already preprocess_depth'ed).  `view_ids` = the Pretrain variant's signature
         (PRE-FF:674-696): view ix looks along heading - view_ids[ix]*pi/6 in the cull as well."""
         batch_depth = np.asarray(batch_depth, F32)
         if view_ids is not None:
             num_of_views = len(view_ids)
+        if batch_extrinsic is not None:                                  # PRE-FF:680-681: all views of the env
+            num_of_views = batch_depth.shape[1]
         for b, e in enumerate(self.env):
             for ix in range(num_of_views):
                 if e.pos.shape[0] == 0:
                     continue
                 # NB: the VLN variant does not add the per-view heading offset here (VLN-FF:347); the Pretrain one does (PRE-FF:696)
-                off = 0.0 if view_ids is None else int(view_ids[ix]) * (-math.pi / 6)
-                mask = G.frustum_mask_habitat(e.pos, batch_depth[b, ix], batch_position[b], off + batch_heading[b],
-                                              self.hfov, self.vfov, 0.0, self.far, 0.1)
+                if batch_extrinsic is not None:                         # get_frustum_mask (PRE-FF:693)
+                    mask = G.frustum_mask_pinhole(e.pos, batch_depth[b, ix], np.asarray(batch_camera_intrinsic[b][ix]),
+                                                  np.asarray(batch_extrinsic[b][ix]), 0.0, self.far, 0.1)
+                else:
+                    off = 0.0 if view_ids is None else int(view_ids[ix]) * (-math.pi / 6)
+                    mask = G.frustum_mask_habitat(e.pos, batch_depth[b, ix], batch_position[b], off + batch_heading[b],
+                                                  self.hfov, self.vfov, 0.0, self.far, 0.1)
                 e.pos[mask] = G.TOMBSTONE
                 e.fts[mask] = 0
                 e.dir[mask] = 0
@@ -150,7 +157,9 @@ class FeatureFieldsOracle:
 
     # ---- update_feature_fields (VLN-FF:493-815) -----------------------------------------------
     @torch.no_grad()
-    def update_feature_fields(self, batch_depth24, batch_grid_ft, patch_segm, batch_position, batch_heading, num_of_views=1, view_ids=None):
+    def update_feature_fields(self, batch_depth24, batch_grid_ft, patch_segm, batch_position=None, batch_heading=None, num_of_views=1,
+                              view_ids=None, batch_camera_intrinsic=None, batch_rot=None, batch_trans=None, depth_scale=1000.0,
+                              depth_trunc=1000.0, view_hw=(12, 12)):
         """batch_depth24 (B,V,P) metres; batch_grid_ft (B,V,P,768); patch_segm (B,V,H,W) or (B*V,1,H,W)
         dense labels; positions habitat xyz; headings rad.  `view_ids` (Pretrain signature, PRE-FF:843,920): view ix looks
         along heading - view_ids[ix]*pi/6 instead of heading - ix*pi/6 (VLN-FF:550); with is_training=False and no GT point
@@ -158,6 +167,10 @@ class FeatureFieldsOracle:
         P = self.H * self.W
         if view_ids is not None:
             num_of_views = len(view_ids)
+        if batch_camera_intrinsic is not None:
+            # intrinsics mode (PRE-FF:849-856, 886-916): `batch_depth24` holds the RAW depth stacks (B,V,Hd,Wd)
+            num_of_views = np.asarray(batch_depth24[0]).shape[0]
+            scale_tan = G.view_scale_tan(np.asarray(batch_camera_intrinsic[0][0]), np.asarray(batch_depth24[0]).shape[-2:], view_hw)
         vid = list(range(num_of_views)) if view_ids is None else [int(v) for v in view_ids]
         segm_all = np.asarray(patch_segm).reshape(self.batch_size, num_of_views, P)
         self.last_debug = []
@@ -165,8 +178,13 @@ class FeatureFieldsOracle:
             for ix in range(num_of_views):
                 dbg = {}
                 proposal_num = min(len(e.members), self.K)
-                pos, direction, scale = G.unproject_habitat(np.asarray(batch_depth24[b][ix], F32), batch_position[b],
-                                                            vid[ix] * (-math.pi / 6) + batch_heading[b], self.H, self.W, self.hfov, self.vfov)
+                if batch_camera_intrinsic is not None:
+                    pos, direction, scale = G.unproject_pinhole(np.asarray(batch_depth24[b][ix]), np.asarray(batch_camera_intrinsic[b][ix]),
+                                                                np.asarray(batch_rot[b][ix]), np.asarray(batch_trans[b][ix]), scale_tan,
+                                                                self.W, depth_scale, depth_trunc, (self.H, self.W))
+                else:
+                    pos, direction, scale = G.unproject_habitat(np.asarray(batch_depth24[b][ix], F32), batch_position[b],
+                                                                vid[ix] * (-math.pi / 6) + batch_heading[b], self.H, self.W, self.hfov, self.vfov)
                 fts16 = np.asarray(batch_grid_ft[b][ix]).astype(np.float16)
                 e.pos = np.concatenate([e.pos, pos], 0)
                 e.dir = np.concatenate([e.dir, direction], 0)

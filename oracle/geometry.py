@@ -242,3 +242,128 @@ def agent_frame(pos: np.ndarray, position_habitat, heading: float, radius: float
         n2 = (((rx * rx).astype(F32) + (ry * ry).astype(F32)).astype(F32) + (pz * pz).astype(F32)).astype(F32)
     keep = np.sqrt(n2).astype(F32) <= F32(radius)
     return rel, keep
+
+
+# =============================================================================================
+# Intrinsics / extrinsics path ("most 3D datasets": posed RGB-D with a pinhole camera)      SURVEY.md 8f-2
+# =============================================================================================
+# ---------------------------------------------------------------------------------------------
+# get_frustum_mask + depth test                                          PRE-FF:98-118, 693-704
+# ---------------------------------------------------------------------------------------------
+def frustum_mask_pinhole(points: np.ndarray, depth_img: np.ndarray, intrinsics: np.ndarray, view_matrix: np.ndarray,
+                         near=0.0, far=3.0, slack=0.1):
+    """points (N,3) world f32; depth_img (H,W) f32 metres; intrinsics (>=3,>=3), view_matrix (4,4) world->camera, f32.
+    `einsum("b c, N c -> N b")` rows: view = fma(V3,1, fma(V2,z, fma(V1,y, V0*x))), uv = fma(K2,Z, fma(K1,Y, K0*X)) -- the
+    accumulation ATen's CPU matmul performs for these shapes (found by matching all 36 000 intermediate values of the
+    golden cases bit for bit) and the one this build's kernel uses (`fmaf`); pinned by tests/golden/g2b_frustum_pinhole.npz,
+    generated by the reference function.  u, v = trunc(uv / uv_z) to int64,
+    `depth` = camera-frame Z; inside = near <= Z <= far, 0 <= u <= W-1, 0 <= v <= H-1; hit = inside & Z < depth[v,u] + slack."""
+    H, W = depth_img.shape
+    K = np.asarray(intrinsics, F32)[:3, :3]
+    V = np.asarray(view_matrix, F32)
+    p = points.astype(F32)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+
+    def fma(a, b, acc):                     # float32 fused multiply-add: the 24x24-bit product is exact in float64
+        return (np.float64(a) * b.astype(np.float64) + acc.astype(np.float64)).astype(F32)
+
+    def row(m, a, b, c, last=None):         # ATen's CPU matmul for these shapes: acc = m0*a, then one FMA per further term
+        s = fma(m[2], c, fma(m[1], b, (m[0] * a).astype(F32)))
+        return s if last is None else fma(last, np.ones_like(a), s)
+
+    with np.errstate(all="ignore"):
+        X, Y, Z = (row(V[r], x, y, z, V[r, 3]) for r in range(3))
+        uh, vh, zh = (row(K[r], X, Y, Z) for r in range(3))
+        uf, vf = (uh / zh).astype(F32), (vh / zh).astype(F32)
+    ok = np.isfinite(uf) & np.isfinite(vf) & (np.abs(uf) < F32(2.0 ** 62)) & (np.abs(vf) < F32(2.0 ** 62))
+    u = np.where(ok, np.trunc(np.where(ok, uf, 0)), -1).astype(np.int64)
+    v = np.where(ok, np.trunc(np.where(ok, vf, 0)), -1).astype(np.int64)
+    inside = ok & (Z >= F32(near)) & (Z <= F32(far)) & (u >= 0) & (u <= W - 1) & (v >= 0) & (v <= H - 1)
+    cam_d = depth_img.astype(F32)[np.clip(v, 0, H - 1), np.clip(u, 0, W - 1)]
+    return inside & (Z < (cam_d + F32(slack)).astype(F32))
+
+
+# ---------------------------------------------------------------------------------------------
+# project_depth_to_3d (Open3D create_from_depth_image + nearest resize)          PRE-FF:81-94
+# ---------------------------------------------------------------------------------------------
+def torch_nearest_indices(src: int, dst: int) -> np.ndarray:
+    """F.interpolate(mode='nearest') source index: min(int(floorf(i * scale)), src-1), scale = float32(src)/dst
+    (ATen `nearest_idx`, float32 arithmetic)."""
+    scale = F32(src) / F32(dst)
+    return np.minimum(np.floor((np.arange(dst, dtype=F32) * scale).astype(F32)).astype(np.int64), src - 1)
+
+
+def project_depth_to_3d(depth: np.ndarray, intrinsic: np.ndarray, depth_scale=1000.0, depth_trunc=1000.0, out_hw=(24, 24)):
+    """depth (H,W) raw sensor units (the reference casts to uint16) -> (points (h*w,3) float64 camera frame, mask).
+
+    PARITY UNPINNED for the Open3D call (open3d==0.18 is not installed; no reference test holds a vector).  Restated from
+    Open3D's published algorithm (PointCloudFactory.cpp, `CreatePointCloudFromFloatDepthImage` after
+    `ConvertDepthToFloatImage`): d = float(uint16) / float(depth_scale), d >= depth_trunc -> 0; pixel (row i, col j) with
+    d > 0 gives z = d, x = (j - cx) * z / fx, y = (i - cy) * z / fy in double; INVALID PIXELS ARE DROPPED, so the reference's
+    `.view(H, W, 3)` raises whenever one exists and its `except` returns all-zero points (PRE-FF:90-91) -- restated as such.
+    Zero pixels are first replaced by the image maximum (PRE-FF:82)."""
+    d = np.array(depth, dtype=np.float64)
+    d[d == 0] = d.max() if d.size else 0
+    u16 = d.astype(np.uint16)
+    f = (u16.astype(F32) / F32(depth_scale)).astype(F32)
+    f[f >= F32(depth_trunc)] = 0
+    H, W = f.shape
+    h, w = out_hw
+    if not np.all(f > 0):
+        pts = np.zeros((h * w, 3), np.float64)
+    else:
+        fx, fy, cx, cy = float(intrinsic[0][0]), float(intrinsic[1][1]), float(intrinsic[0][2]), float(intrinsic[1][2])
+        ri, ci = torch_nearest_indices(H, h), torch_nearest_indices(W, w)
+        z = f[np.ix_(ri, ci)].astype(np.float64)
+        x = (ci[None, :].astype(np.float64) - cx) * z / fx
+        y = (ri[:, None].astype(np.float64) - cy) * z / fy
+        pts = np.stack([x, y, z], -1).reshape(-1, 3)
+    return pts, pts[:, 2] > 0.002
+
+
+def heading_angle(position: np.ndarray) -> np.ndarray:
+    """Feature_Fields.get_heading_angle (PRE-FF:378-387), dtype-preserving like the reference (float64 in, float64 out)."""
+    dx, dy = position[:, 0], position[:, 1]
+    xy = np.sqrt(np.square(dx) + np.square(dy))
+    xy[xy < 1e-4] = 1e-4
+    h = -np.arcsin(dx / xy)
+    h[dy < 0] = h[dy < 0] - np.pi
+    return h
+
+
+def rays_pinhole(fx: float, fy: float, view_h=12, view_w=12, near=0.0, far=10.0, n_samples=501):
+    """Feature_Fields.get_rays (PRE-FF:390-405): N constant-depth float32 images at near + spacing*(i+1) unprojected with
+    PinholeCameraIntrinsic(view_w, view_h, fx, fy, view_w/2, view_h/2) (Open3D: double arithmetic on the float32 depth).
+    -> rel_position (R,N,3) f64, rel_direction (R,1) f64 = -arctan(x/z) of the last sample, rel_dist (R,N) f64."""
+    spacing = (far - near) / n_samples
+    z = np.array([F32(near + spacing * (i + 1)) for i in range(n_samples)], np.float64)       # np.full(..., dtype=float32)
+    jj, ii = np.meshgrid(np.arange(view_w, dtype=np.float64), np.arange(view_h, dtype=np.float64))
+    cx, cy = view_w / 2, view_h / 2
+    x = (jj.reshape(-1, 1) - cx) * z[None, :] / fx
+    y = (ii.reshape(-1, 1) - cy) * z[None, :] / fy
+    rel = np.stack([x, y, np.broadcast_to(z[None, :], x.shape)], -1)
+    return rel, -np.arctan(rel[:, -1:, 0] / rel[:, -1:, 2]), rel[..., 2].copy()
+
+
+def unproject_pinhole(depth: np.ndarray, intrinsic: np.ndarray, R: np.ndarray, T: np.ndarray, scale_tan: float, input_width=24,
+                      depth_scale=1000.0, depth_trunc=1000.0, out_hw=(24, 24)):
+    """Per-view patch geometry of the intrinsics branch of update_feature_fields (PRE-FF:905-916):
+    scale = z32 * |tan(rel_direction[0][-1])| * 2 / input_width (float32 array ops), world = R @ p32 + T (float64, then
+    float32), direction = get_heading_angle(world) (float64, then float32).  `scale_tan` = |tan(rel_direction[0][-1])| of the
+    rays built from the view-sized intrinsics (PRE-FF:849-856)."""
+    pts, _ = project_depth_to_3d(depth, intrinsic, depth_scale, depth_trunc, out_hw)
+    p32 = pts.astype(F32)
+    sc = (p32[:, -1] * F32(scale_tan)).astype(F32)
+    sc = (sc * F32(2.0)).astype(F32)
+    sc = (sc / F32(input_width)).astype(F32)
+    world = (np.asarray(R, np.float64) @ p32.T.astype(np.float64) + np.asarray(T, np.float64).reshape(3, 1)).T
+    return world.astype(F32), heading_angle(world).astype(F32), sc
+
+
+def view_scale_tan(intrinsic: np.ndarray, depth_hw, view_hw=(12, 12)) -> float:
+    """|tan(rel_direction[0][-1])| for the rays of `init_camera_intrinsic` (PRE-FF:849-856): fx scaled by view_w / depth_W,
+    principal point view_w/2; ray 0 is pixel (0,0): rel_direction = -arctan(((0 - cx) * z / fx) / z)."""
+    fx = float(intrinsic[0][0]) * (view_hw[1] / depth_hw[1])
+    z = float(F32(10.0))
+    x = (0.0 - view_hw[1] / 2) * z / fx
+    return math.fabs(math.tan(float(-np.arctan(x / z))))

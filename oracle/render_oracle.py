@@ -151,3 +151,29 @@ def render_view(patch_pos, patch_dir, patch_scale, patch_fts16, sd, position_hab
     fm, depth = raw2feature(feat, dens, rel_y, topk)
     return dict(feature_map=fm.numpy().reshape(H, W, -1), positions=sample_xyz[:, 0].reshape(H, W, 3), depth=depth.numpy().reshape(H, W),
                 topk=topk, n_ranked=n_ranked, geom6=geom6, density=dens.float().numpy(), feat=feat.float().numpy(), sidx=sidx)
+
+
+def render_view_pinhole(patch_pos, patch_dir, patch_scale, patch_fts16, sd, rot, trans, fx, fy, H=12, W=12, n_samples=501, n_imp=8, k=4,
+                        radius=1.0, near=0.0, far=10.0):
+    """Intrinsics mode of render_view_3d_patch (PRE-FF:505-515, 532-536), one environment: rays from get_rays(init_camera_intrinsic)
+    (oracle/geometry.py::rays_pinhole; Open3D restated, PARITY UNPINNED), world = R @ rel + T in double then float32, camera heading
+    = float32(get_heading_angle(R @ [0,0,1] + T)) -- of the world POINT, translation included, as the reference does -- and the
+    rest as `render_view`.  The ray's own direction enters the neighbour geometry as float64 in the reference (PRE-FF:603-605) and
+    as float32 here: a 6e-8 rad difference, inside the test tolerance."""
+    rel, rel_dir, rel_dist = G.rays_pinhole(fx, fy, H, W, near, far, n_samples)
+    R_ = H * W
+    Rm, T = np.asarray(rot, np.float64).reshape(3, 3), np.asarray(trans, np.float64).reshape(3, 1)
+    ray = (Rm @ rel.reshape(-1, 3).T + T).T.astype(F32).reshape(R_, n_samples, 3)
+    fwd = (Rm @ np.array([[0.0, 0.0, 1.0]]).T + T).T
+    heading = float(F32(G.heading_angle(fwd)[0]))
+    d2, idx = G.knn_bruteforce(patch_pos, ray.reshape(-1, 3), k)
+    idx_m, topk, n_ranked = ray_topk(d2, idx, R_, n_samples, radius, n_imp)
+    sample_xyz = np.take_along_axis(ray, topk[..., None].repeat(3, -1), 1)
+    sidx = np.take_along_axis(idx_m, topk[..., None].repeat(k, -1), 1)
+    geom6 = neighbour_geometry(patch_pos, patch_dir, patch_scale, sample_xyz, sidx, heading, rel_dir.astype(F32), far)
+    emb = patch_fts16[np.where(sidx < 0, 0, sidx)].astype(np.float16)
+    emb[sidx < 0] = 0
+    feat, dens = nerf_encode(torch.from_numpy(emb), torch.from_numpy(geom6), sd, n_imp)
+    fm, depth = raw2feature(feat, dens, rel_dist, topk)
+    return dict(feature_map=fm.numpy().reshape(H, W, -1), positions=sample_xyz[:, 0].reshape(H, W, 3), depth=depth.numpy().reshape(H, W),
+                topk=topk, n_ranked=n_ranked, heading=heading, ray=ray)

@@ -112,6 +112,39 @@ class CpuOps:
     def frustum_mask(self, points, depth, pose_host, intr, near, far, slack):
         return torch.from_numpy(self._mask(_np(points), _np(depth), _Pose(np.asarray(pose_host, F32)), intr, near, far, slack).astype(np.uint8))
 
+    # intrinsics / extrinsics path: same packed camera rows as the HIP entry points
+    def frustum_cull_pinhole(self, pools: Pools, slot, n_rows, max_rows, depth, views, near, far, slack, hits, n_hits, mask=None):
+        sl, nr, vw, dp = _np(slot), _np(n_rows), _np(views), _np(depth)
+        for e in range(len(sl)):
+            pts = pools.rows_pos[sl[e], :nr[e]].numpy()
+            V = np.concatenate([vw[e, :12].reshape(3, 4), [[0, 0, 0, 1]]]).astype(F32)
+            m = G.frustum_mask_pinhole(pts, dp[e], vw[e, 12:].reshape(3, 3), V, near, far, slack)
+            idx = np.random.default_rng(int(nr[e])).permutation(np.nonzero(m)[0])
+            hits[e, :len(idx)] = torch.from_numpy(idx.astype(np.int32))
+            n_hits[e] = len(idx)
+            mt = torch.from_numpy(m)
+            pools.rows_pos[sl[e], :nr[e]][mt] = -10000.0
+            pools.rows_fts[sl[e], :nr[e]][mt] = 0
+            pools.rows_dir[sl[e], :nr[e]][mt] = 0
+            pools.rows_scale[sl[e], :nr[e]][mt] = 0
+
+    def frustum_mask_pinhole(self, points, depth, view_host, near, far, slack):
+        vw = np.asarray(view_host, F32).reshape(-1)
+        V = np.concatenate([vw[:12].reshape(3, 4), [[0, 0, 0, 1]]]).astype(F32)
+        return torch.from_numpy(G.frustum_mask_pinhole(_np(points), _np(depth), vw[12:].reshape(3, 3), V, near, far, slack).astype(np.uint8))
+
+    def unproject_pinhole_append(self, depth, cams, slot, row_base, h, w, input_width, pools: Pools):
+        d, cm, sl, rb = _np(depth), _np(cams), _np(slot), _np(row_base)
+        for e in range(d.shape[0]):
+            K = np.array([[cm[e, 0], 0, cm[e, 2]], [0, cm[e, 1], cm[e, 3]], [0, 0, 1]])
+            scale_tan, depth_scale, depth_trunc, _ = np.ascontiguousarray(cm[e, 16:18]).view(F32)
+            pos, direction, sc = G.unproject_pinhole(d[e], K, cm[e, 4:13].reshape(3, 3), cm[e, 13:16], scale_tan, input_width,
+                                                     depth_scale, depth_trunc, (h, w))
+            r0, P = int(rb[e]), h * w
+            pools.rows_pos[sl[e], r0:r0 + P] = torch.from_numpy(pos)
+            pools.rows_dir[sl[e], r0:r0 + P] = torch.from_numpy(direction)
+            pools.rows_scale[sl[e], r0:r0 + P] = torch.from_numpy(sc)
+
     # a8
     def knn(self, points, point_stride, n_points, queries, query_stride, n_queries, k, n_batch, max_queries, k_max):
         pts, q = _np(points).reshape(-1), _np(queries).reshape(-1)

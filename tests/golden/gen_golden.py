@@ -91,6 +91,49 @@ def g2_frustum():
     print("g2 ok", [int(cases[f'mask_{i}'].sum()) for i in range(n)])
 
 
+def g2b_frustum_pinhole():
+    """Intrinsics/extrinsics cull (PRE-FF:98-118 + the depth test of PRE-FF:699-704) and get_heading_angle (PRE-FF:378-387),
+    both executed by the reference's Pretrain module."""
+    m = rh.load_ref_module("pre")
+    sys.argv = ["x"]
+    F = m.Feature_Fields(batch_size=1, device="cpu")
+    rng = np.random.default_rng(250)
+    cases = {}
+    n = 0
+    for (Hd, Wd), N in [((48, 64), 3000), ((480, 640), 4000), ((240, 320), 3000)]:
+        ang = rng.uniform(0, 2 * math.pi, 3)
+        cz, sz = math.cos(ang[0]), math.sin(ang[0])
+        cy_, sy = math.cos(ang[1] * 0.2), math.sin(ang[1] * 0.2)
+        Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        Ry = np.array([[cy_, 0, sy], [0, 1, 0], [-sy, 0, cy_]])
+        R = Rz @ Ry                                               # camera -> world
+        T = rng.uniform(-1.5, 1.5, 3)
+        view = np.eye(4)
+        view[:3, :3], view[:3, 3] = R.T, -R.T @ T                 # world -> camera
+        K = np.eye(4)
+        K[0, 0], K[1, 1], K[0, 2], K[1, 2] = 0.9 * Wd, 0.9 * Wd, Wd / 2 - 0.5, Hd / 2 + 0.25
+        cam_pts = np.stack([rng.uniform(-3, 3, N), rng.uniform(-3, 3, N), rng.uniform(-1, 5, N)], -1)
+        pts = (R @ cam_pts.T + T[:, None]).T.astype(np.float32)
+        pts[:40] = -10000.0
+        pts[40:44] = T.astype(np.float32)                         # camera centre: z = 0 -> inf / nan quotients
+        dimg = rng.uniform(0.3, 4.0, (Hd, Wd)).astype(np.float32)
+        tp = torch.tensor(pts)
+        mask, depth, u, v = m.get_frustum_mask(tp, Hd, Wd, torch.tensor(K, dtype=torch.float32), torch.tensor(view, dtype=torch.float32), far=3.0)
+        uu, vv = u % Wd, v % Hd
+        fm = (mask & (depth < torch.tensor(dimg)[vv, uu] + 0.1)).numpy()
+        cases[f"pts_{n}"], cases[f"depth_{n}"], cases[f"K_{n}"], cases[f"view_{n}"] = pts, dimg, K.astype(np.float32), view.astype(np.float32)
+        cases[f"mask_{n}"] = fm
+        n += 1
+    cases["n"] = np.int64(n)
+    hp = rng.uniform(-4, 4, (400, 3))
+    hp[:8, :2] *= 1e-6                                            # xy_dist < 1e-4 clamp
+    hp[8:12, 1] = 0.0
+    cases["heading_pts"] = hp
+    cases["heading_out"] = F.get_heading_angle(hp.copy())
+    np.savez_compressed(os.path.join(OUT, "g2b_frustum_pinhole.npz"), **cases)
+    print("g2b ok", [int(cases[f'mask_{i}'].sum()) for i in range(n)])
+
+
 def g3_knn():
     rng = np.random.default_rng(300)
     cases = {}
@@ -216,6 +259,6 @@ def g7_text_to_action():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7"]
     torch.set_num_threads(8)
-    fns = {"g1": g1_unproject, "g2": g2_frustum, "g3": g3_knn, "g4": g4_trajectories, "g7": g7_text_to_action}
+    fns = {"g1": g1_unproject, "g2": g2_frustum, "g2b": g2b_frustum_pinhole, "g3": g3_knn, "g4": g4_trajectories, "g7": g7_text_to_action}
     for w in which:
         fns[w]()
