@@ -178,6 +178,7 @@ class HipOps:
                                            self._stream()))
 
     def frustum_mask(self, points, depth, pose_host: np.ndarray, intr, near, far, slack):
+        points, depth = points.contiguous(), depth.contiguous()
         N = points.shape[0]
         Hd, Wd = depth.shape
         mask = torch.empty(N, dtype=torch.uint8, device=points.device)
@@ -196,6 +197,7 @@ class HipOps:
                                                    near, far, slack, _ptr(hits), _ptr(n_hits), hits.shape[1], _ptr(mask), self._stream()))
 
     def frustum_mask_pinhole(self, points, depth, view_host: np.ndarray, near, far, slack):
+        points, depth = points.contiguous(), depth.contiguous()
         N = points.shape[0]
         Hd, Wd = depth.shape
         mask = torch.empty(N, dtype=torch.uint8, device=points.device)
