@@ -23,6 +23,7 @@ SIGNATURES = {
     "d3d_patch_3d_info": [vp, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp],
     "d3d_frustum_cull": [vp, vp, vp, vp, i64, vp, vp, i32, i32, vp, i32, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp, i32, vp, vp],
     "d3d_frustum_mask": [vp, i64, vp, i32, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp],
+    "d3d_patch_segm_from_masks": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "d3d_frustum_cull_pinhole": [vp, vp, vp, vp, i64, vp, vp, i32, i32, vp, i32, i32, vp, f32, f32, f32, vp, vp, i32, vp, vp],
     "d3d_frustum_mask_pinhole": [vp, i64, vp, i32, i32, vp, f32, f32, f32, vp, vp],
     "d3d_unproject_pinhole_append": [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i64, vp],

@@ -82,6 +82,70 @@ __global__ void k_resize_preprocess(const float* __restrict__ in, float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// a6 get_patch_segm after the segmenter (VLN-FF:407-420): one block per image.  Only the h*w pixels that the nearest resize
+// samples are looked at: for each, the LAST mask that covers it (none -> group 0), then labels -> rank among the labels
+// present (torch.unique order).  masks: (total,H,W) u8 {0,1}, image i owns masks [off[i], off[i+1]).
+// ------------------------------------------------------------------------------------------------
+constexpr int SEGM_MAX_MASKS = 4096;
+
+__global__ void __launch_bounds__(256)
+k_patch_segm(const uint8_t* __restrict__ masks, const int32_t* __restrict__ off, int H, int W, int h, int w,
+             int32_t* __restrict__ segm, int32_t* __restrict__ n_seg) {
+    __shared__ int32_t rank[SEGM_MAX_MASKS];          // present flag, then exclusive rank
+    __shared__ int32_t wsum[4];
+    extern __shared__ int32_t label[];                // h*w
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int m0 = off[img], nm = off[img + 1] - m0;
+    for (int g = tid; g < nm; g += 256) rank[g] = 0;
+    if (nm == 0 && tid == 0) rank[0] = 0;
+    __syncthreads();
+    const float sy = (float)H / (float)h, sx = (float)W / (float)w;        // ATen nearest: float32 scale
+    const size_t plane = (size_t)H * W;
+    for (int p = tid; p < h * w; p += 256) {
+        const int r = p / w, c = p % w;
+        int sr = (int)floorf((float)r * sy), sc = (int)floorf((float)c * sx);
+        sr = sr < H - 1 ? sr : H - 1;
+        sc = sc < W - 1 ? sc : W - 1;
+        const uint8_t* px = masks + (size_t)m0 * plane + (size_t)sr * W + sc;
+        int lab = 0;
+        for (int g = nm - 1; g > 0; --g)
+            if (px[(size_t)g * plane] == 1) {
+                lab = g;
+                break;
+            }
+        label[p] = lab;
+        rank[lab] = 1;                                  // benign race: every writer stores 1
+    }
+    __syncthreads();
+    // exclusive scan of the present flags (nm <= 4096: 16 flags per thread, wave scan, 4 wave sums)
+    constexpr int PER = SEGM_MAX_MASKS / 256;
+    const int lim = nm > 0 ? nm : 1;
+    int loc[PER], tot = 0;
+    for (int j = 0; j < PER; ++j) {
+        const int g = tid * PER + j;
+        loc[j] = tot;
+        tot += (g < lim) ? rank[g] : 0;
+    }
+    int incl = tot;
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if ((tid & (WAVE - 1)) >= o) incl += v;
+    }
+    if ((tid & (WAVE - 1)) == WAVE - 1) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = incl - tot;
+    for (int wv = 0; wv < (tid >> 6); ++wv) base += wsum[wv];
+    __syncthreads();
+    for (int j = 0; j < PER; ++j) {
+        const int g = tid * PER + j;
+        if (g < lim) rank[g] = base + loc[j];
+    }
+    if (tid == 255) n_seg[img] = base + tot;
+    __syncthreads();
+    for (int p = tid; p < h * w; p += 256) segm[(size_t)img * h * w + p] = rank[label[p]];
+}
+
+// ------------------------------------------------------------------------------------------------
 // a5 unprojection + append
 // ------------------------------------------------------------------------------------------------
 __global__ void k_unproject_append(const float* __restrict__ depth24, const d3d_pose* __restrict__ pose,
@@ -691,6 +755,18 @@ int32_t d3d_unproject_append(const float* depth24, const d3d_pose* pose, const i
     if (n_env <= 0) return D3D_OK;
     hipLaunchKernelGGL(k_unproject_append, dim3(n_env), dim3(576), 0, (hipStream_t)stream, depth24, pose, slot, row_base, P, W,
                        tan_xy, tan_z, dir0, th, rows_pos, rows_dir, rows_scale, n_cap);
+    D3D_LAUNCH_CHECK();
+}
+
+int32_t d3d_patch_segm_from_masks(const uint8_t* masks, const int32_t* mask_off, int32_t n_img, int32_t max_masks, int32_t H, int32_t W,
+                                  int32_t h, int32_t w, int32_t* segm, int32_t* n_seg, void* stream) {
+    if (n_img <= 0) return D3D_OK;
+    if (max_masks > SEGM_MAX_MASKS || h * w > 4096 || H <= 0 || W <= 0) {
+        d3d_set_error_("d3d_patch_segm_from_masks: at most 4096 masks per image and 4096 patches");
+        return D3D_EINVAL;
+    }
+    hipLaunchKernelGGL(k_patch_segm, dim3(n_img), dim3(256), (size_t)h * w * sizeof(int32_t), (hipStream_t)stream, masks, mask_off, H, W, h, w,
+                       segm, n_seg);
     D3D_LAUNCH_CHECK();
 }
 

@@ -188,6 +188,19 @@ class HipOps:
                                            near, far, slack, _ptr(mask), self._stream()))
         return mask
 
+    # -- a6 (after the segmenter network) ---------------------------------------------------------------
+    def patch_segm_from_masks(self, masks: torch.Tensor, mask_off: Sequence[int], h: int, w: int):
+        """masks (total,H,W) uint8 {0,1} on the device; mask_off (n_img+1) host ints -> (segm (n_img,1,h,w) int64, n_seg (n_img,) int32)."""
+        n_img = len(mask_off) - 1
+        assert masks.dtype == torch.uint8 and masks.is_contiguous()
+        _, H, W = masks.shape
+        off = torch.tensor(list(mask_off), dtype=torch.int32, device=masks.device)
+        segm = torch.empty((n_img, h * w), dtype=torch.int32, device=masks.device)
+        n_seg = torch.empty((n_img,), dtype=torch.int32, device=masks.device)
+        mx = max([mask_off[i + 1] - mask_off[i] for i in range(n_img)] + [0])
+        self._ck(self.lib.d3d_patch_segm_from_masks(_ptr(masks), _ptr(off), n_img, mx, H, W, h, w, _ptr(segm), _ptr(n_seg), self._stream()))
+        return segm.view(n_img, 1, h, w).long(), n_seg
+
     # -- intrinsics / extrinsics path (SURVEY.md 8f-2) --------------------------------------------------
     def frustum_cull_pinhole(self, pools: Pools, slot, n_rows, max_rows, depth, views, near, far, slack, hits, n_hits, mask=None):
         """views: (n_env, 21) float32 device tensor = d3d_pinhole_view rows (see `pinhole_views`)."""

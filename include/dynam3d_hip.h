@@ -63,6 +63,13 @@ int32_t d3d_preprocess_depth(const float* depth_d, float* out_d, int32_t B, int3
 int32_t d3d_resize_nearest_preprocess(const float* depth_d, float* out_d, int32_t B, int32_t H, int32_t W,
                                       int32_t h, int32_t w, float lo, float hi, void* stream);
 
+/* a6  get_patch_segm after the segmenter network (VLN-FF:407-420): 'last mask wins' label image -> nearest (h,w) resize
+ * (F.interpolate, ATen float32 index rule) -> labels replaced by their rank in torch.unique order.  masks_d (total,H,W) u8
+ * {0,1}; image i owns masks [mask_off_d[i], mask_off_d[i+1]) (none -> all zeros, the reference's except branch,
+ * VLN-FF:424-426); segm_d (n_img, h*w) i32, n_seg_d (n_img) = number of dense labels.  max_masks = host-side bound. */
+int32_t d3d_patch_segm_from_masks(const uint8_t* masks_d, const int32_t* mask_off_d, int32_t n_img, int32_t max_masks,
+                                  int32_t H, int32_t W, int32_t h, int32_t w, int32_t* segm_d, int32_t* n_seg_d, void* stream);
+
 /* camera tables for a5/a13 are uploaded once per camera setting by the host wrapper:
  * tan_xy[P], tan_z[P], dir0[P] (see oracle/geometry.py::camera_tables; VLN-FF:283-287). */
 

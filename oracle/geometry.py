@@ -367,3 +367,25 @@ def view_scale_tan(intrinsic: np.ndarray, depth_hw, view_hw=(12, 12)) -> float:
     z = float(F32(10.0))
     x = (0.0 - view_hw[1] / 2) * z / fx
     return math.fabs(math.tan(float(-np.arctan(x / z))))
+
+
+# ---------------------------------------------------------------------------------------------
+# a6  get_patch_segm post-processing (everything after FastSAM)                   VLN-FF:407-420
+# ---------------------------------------------------------------------------------------------
+def patch_segm_from_masks(masks: np.ndarray, out_hw=(24, 24)) -> np.ndarray:
+    """masks (n,H,W) in {0,1} (FastSAM 'everything' masks) -> dense labels (1,h,w) int64.
+    patch_group starts as masks[0] and every mask g overwrites its pixels with g ('last mask wins'; uncovered pixels keep
+    masks[0]'s 0, i.e. they join group 0); F.interpolate(mode='nearest') to (h,w) (ATen float32 index rule); labels replaced
+    by their rank in torch.unique (sorted) order.  No masks -> the reference's `masks[0]` raises -> all zeros (VLN-FF:424-426)."""
+    h, w = out_hw
+    if masks.shape[0] == 0:
+        return np.zeros((1, h, w), np.int64)
+    group = masks[0].astype(np.float32).copy()
+    for g in range(masks.shape[0]):
+        group[masks[g] == 1] = g
+    ri, ci = torch_nearest_indices(masks.shape[1], h), torch_nearest_indices(masks.shape[2], w)
+    small = group[np.ix_(ri, ci)].astype(np.int64)
+    out = small.copy()
+    for rank, lab in enumerate(np.unique(small).tolist()):
+        out[small == lab] = rank
+    return out[None]

@@ -112,6 +112,13 @@ class CpuOps:
     def frustum_mask(self, points, depth, pose_host, intr, near, far, slack):
         return torch.from_numpy(self._mask(_np(points), _np(depth), _Pose(np.asarray(pose_host, F32)), intr, near, far, slack).astype(np.uint8))
 
+    # a6 after the segmenter
+    def patch_segm_from_masks(self, masks, mask_off, h, w):
+        mk = _np(masks)
+        out = [G.patch_segm_from_masks(mk[mask_off[i]:mask_off[i + 1]], (h, w)) for i in range(len(mask_off) - 1)]
+        segm = torch.from_numpy(np.stack(out))
+        return segm, torch.tensor([int(o.max()) + 1 for o in out], dtype=torch.int32)
+
     # intrinsics / extrinsics path: same packed camera rows as the HIP entry points
     def frustum_cull_pinhole(self, pools: Pools, slot, n_rows, max_rows, depth, views, near, far, slack, hits, n_hits, mask=None):
         sl, nr, vw, dp = _np(slot), _np(n_rows), _np(views), _np(depth)

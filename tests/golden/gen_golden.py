@@ -228,6 +228,56 @@ def g4_trajectories():
     print("g4 ok")
 
 
+def synth_masks(rng, n, H, W):
+    """Overlapping random rectangles / discs as FastSAM 'everything' masks: float32 {0,1}, (n,H,W)."""
+    yy, xx = np.mgrid[0:H, 0:W]
+    out = np.zeros((n, H, W), np.float32)
+    for i in range(n):
+        cy, cx = rng.uniform(0, H), rng.uniform(0, W)
+        if i % 2:
+            out[i] = ((yy - cy) ** 2 + (xx - cx) ** 2 < rng.uniform(0.05, 0.4) ** 2 * H * W).astype(np.float32)
+        else:
+            h, w = rng.uniform(0.1, 0.6) * H, rng.uniform(0.1, 0.6) * W
+            out[i] = ((np.abs(yy - cy) < h / 2) & (np.abs(xx - cx) < w / 2)).astype(np.float32)
+    return out
+
+
+def g10_patch_segm():
+    """a6: the reference's own `get_patch_segm` (VLN-FF:399-430) with FastSAM's output injected: 'last mask wins' label image ->
+    nearest 24x24 -> dense relabel in torch.unique order; a failing segmenter -> zeros."""
+    m = rh.load_ref_module("vln")
+    sys.argv = ["x"]
+    F = m.Feature_Fields(batch_size=1, device="cpu")
+    rng = np.random.default_rng(1000)
+    cases = {}
+    queue = []
+
+    class Prompt:
+        def __init__(self, *a, **k):
+            pass
+
+        def everything_prompt(self):
+            mk = queue.pop(0)
+            if mk is None:
+                raise RuntimeError("no masks")
+            return torch.from_numpy(mk)
+
+    m.FastSAMPrompt = Prompt
+    F.FastSAM = lambda *a, **k: None
+    specs = [(5, 224, 224), (40, 224, 224), (1, 100, 60), (17, 480, 640), (0, 64, 64), (90, 336, 336), (3, 24, 24), (12, 37, 51)]
+    for i, (n, H, W) in enumerate(specs):
+        mk = synth_masks(rng, n, H, W) if n else None
+        if i == 2:
+            mk[:] = 0                                                    # one all-empty mask
+        queue.append(mk)
+        out = m.Feature_Fields.get_patch_segm(F, [np.zeros((H, W, 3), np.uint8)])
+        cases[f"masks_{i}"] = np.zeros((0, H, W), np.uint8) if mk is None else mk.astype(np.uint8)
+        cases[f"segm_{i}"] = out.numpy()
+    cases["n"] = np.int64(len(specs))
+    np.savez_compressed(os.path.join(OUT, "g10_patch_segm.npz"), **cases)
+    print("g10 ok", [int(cases[f"segm_{i}"].max()) + 1 for i in range(len(specs))])
+
+
 def g7_text_to_action():
     """Executes the reference's own `convert_text_to_action` (VLN-POL:472-506): the module cannot
     be imported (habitat/gym/cv2/peft), so the single FunctionDef is located with `ast` and
@@ -259,6 +309,6 @@ def g7_text_to_action():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7"]
     torch.set_num_threads(8)
-    fns = {"g1": g1_unproject, "g2": g2_frustum, "g2b": g2b_frustum_pinhole, "g3": g3_knn, "g4": g4_trajectories, "g7": g7_text_to_action}
+    fns = {"g1": g1_unproject, "g2": g2_frustum, "g2b": g2b_frustum_pinhole, "g3": g3_knn, "g4": g4_trajectories, "g7": g7_text_to_action, "g10": g10_patch_segm}
     for w in which:
         fns[w]()

@@ -1,0 +1,56 @@
+"""a6: get_patch_segm post-processing (VLN-FF:407-420) -- oracle vs the golden produced by the reference's own function with
+FastSAM's output injected; the MaskSegmenter wrapper on the CPU test double and, on the GPU, `d3d_patch_segm_from_masks`."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry as G
+from tests.golden_io import load
+
+
+def _cases():
+    g = load("g10_patch_segm.npz")
+    return [(g[f"masks_{i}"], g[f"segm_{i}"]) for i in range(int(g["n"]))]
+
+
+def test_oracle_patch_segm_matches_reference_golden():
+    for masks, ref in _cases():
+        assert np.array_equal(G.patch_segm_from_masks(masks), ref[0])
+
+
+def _run_segmenter(ops, device):
+    from dynam3d_amd.segm import MaskSegmenter
+    cases = _cases()
+    by_shape = {}
+    for masks, ref in cases:
+        by_shape.setdefault(masks.shape[1:], []).append((masks, ref))
+    for shape, items in by_shape.items():                          # one batched launch per mask resolution
+        table = {id(m): m for m, _ in items}
+        seg = MaskSegmenter(lambda img: table[img], ops, device=device)
+        out = seg([id(m) for m, _ in items]).cpu().numpy()
+        for j, (_, ref) in enumerate(items):
+            assert np.array_equal(out[j], ref[0]), shape
+
+    def boom(img):
+        raise RuntimeError("segmenter failed")
+    assert not MaskSegmenter(boom, ops, device=device)([0, 1]).any()           # VLN-FF:424-426
+
+
+def test_mask_segmenter_cpu_double():
+    from tests.cpu_ops import CpuOps
+    _run_segmenter(CpuOps(), "cpu")
+
+
+@pytest.mark.gpu
+def test_patch_segm_kernel_matches_reference_golden():
+    from dynam3d_amd.ops import HipOps
+    _run_segmenter(HipOps(), "cuda")
+    # many masks, ragged batch incl. an image without masks
+    ops = HipOps()
+    rng = np.random.default_rng(5)
+    sets = [(rng.random((n, 96, 128)) < 0.02).astype(np.uint8) for n in (700, 0, 33, 1)]
+    off = np.concatenate([[0], np.cumsum([len(s) for s in sets])]).tolist()
+    segm, n_seg = ops.patch_segm_from_masks(torch.from_numpy(np.concatenate(sets)).cuda(), off, 24, 24)
+    for i, s in enumerate(sets):
+        ref = G.patch_segm_from_masks(s)
+        assert np.array_equal(segm[i].cpu().numpy(), ref) and int(n_seg[i]) == int(ref.max()) + 1
