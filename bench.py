@@ -188,6 +188,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
     DD.barrier()
+    DD.shutdown()
 
 
 if __name__ == "__main__":

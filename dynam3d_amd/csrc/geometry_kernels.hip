@@ -28,18 +28,30 @@ __device__ __forceinline__ float pymodf(float a, float b) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// a1 preprocess_depth: one thread per (b, column); two passes over H (max, then map)
+// a1 preprocess_depth: block = 32 columns x 8 row groups of one image; column maxima combined through LDS (max is
+// order-independent), then the same threads map their rows.  (One thread per column walked H rows alone: 206 us for a
+// 224x224 batch of 8, all of it load latency.)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_preprocess_depth(const float* __restrict__ in, float* __restrict__ out, int H, int W, float range,
-                                   float lo100) {
+constexpr int PD_COLS = 32, PD_GROUPS = 8;
+
+__global__ void __launch_bounds__(PD_COLS * PD_GROUPS)
+k_preprocess_depth(const float* __restrict__ in, float* __restrict__ out, int H, int W, float range, float lo100) {
+    __shared__ float part[PD_GROUPS][PD_COLS];
     const int b = blockIdx.y;
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W) return;
+    const int c = threadIdx.x % PD_COLS, g = threadIdx.x / PD_COLS;
+    const int w = blockIdx.x * PD_COLS + c;
+    const bool live = w < W;
     const float* src = in + (size_t)b * H * W + w;
     float* dst = out + (size_t)b * H * W + w;
     float mx = -INFINITY;
-    for (int h = 0; h < H; ++h) mx = fmaxf(mx, src[(size_t)h * W] * 1.0f);
-    for (int h = 0; h < H; ++h) {
+    if (live)
+        for (int h = g; h < H; h += PD_GROUPS) mx = fmaxf(mx, src[(size_t)h * W] * 1.0f);
+    part[g][c] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PD_GROUPS; ++j) mx = fmaxf(mx, part[j][c]);
+    if (!live) return;
+    for (int h = g; h < H; h += PD_GROUPS) {
         float d = src[(size_t)h * W] * 1.0f;
         if (d == 0.0f) d = mx;
         float t = d * range;
@@ -735,8 +747,8 @@ int32_t d3d_device_info(int32_t* n_cu, int32_t* wave_size, int32_t* lds_bytes) {
 int32_t d3d_preprocess_depth(const float* depth, float* out, int32_t B, int32_t H, int32_t W, float lo, float hi, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0) return D3D_OK;
     const float range = (float)((double)hi - (double)lo), lo100 = (float)((double)lo * 100.0);
-    dim3 grid((W + 255) / 256, B);
-    hipLaunchKernelGGL(k_preprocess_depth, grid, dim3(256), 0, (hipStream_t)stream, depth, out, H, W, range, lo100);
+    dim3 grid((W + PD_COLS - 1) / PD_COLS, B);
+    hipLaunchKernelGGL(k_preprocess_depth, grid, dim3(PD_COLS * PD_GROUPS), 0, (hipStream_t)stream, depth, out, H, W, range, lo100);
     D3D_LAUNCH_CHECK();
 }
 

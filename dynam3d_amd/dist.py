@@ -55,3 +55,10 @@ def barrier():
             dist.barrier(device_ids=[torch.cuda.current_device()])      # pin the collective to this rank's GPU
         else:
             dist.barrier()
+
+
+def shutdown():
+    """Tear the process group down before interpreter exit (RCCL communicators are otherwise destroyed by atexit handlers in an
+    unspecified order, which newer PyTorch versions warn about)."""
+    if dist.is_initialized():
+        dist.destroy_process_group()
