@@ -13,7 +13,13 @@ from typing import List, Sequence
 
 import torch
 
+import ctypes as C
+
+from . import _lib
 from .hip_dense import HipDense
+
+_lib.register("d3d_mlp768_forward", [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 
 
 class Network:
@@ -60,11 +66,15 @@ class Network:
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """One C call (`d3d_mlp768_forward`): n_hidden + 1 fused GEMM + activation launches."""
         h = x.to(self.device, torch.float16).contiguous()
-        last = len(self.w) - 1
-        for i, w in enumerate(self.w):
-            a = self.act if i < last else self.out_act
-            h = self.hd.gemm(h[:, : w.shape[1]] if h.shape[1] != w.shape[1] else h, w, None, None, "lrelu" if a == "LeakyReLU" else "none")
-        return h[:, : self.n_output_dims]
+        n, nn_, n_pad = h.shape[0], self.dims[1], self.w[-1].shape[0]
+        y = torch.empty((n, n_pad), dtype=torch.float16, device=self.device)
+        sa, sb = (torch.empty((n, nn_), dtype=torch.float16, device=self.device) for _ in range(2))
+        ptrs = (C.c_void_p * len(self.w))(*[w.data_ptr() for w in self.w])
+        lk = lambda a: 1 if a == "LeakyReLU" else 0
+        _lib.check(self.hd.lib.d3d_mlp768_forward(h.data_ptr(), n, self.dims[0], ptrs, len(self.w) - 1, nn_, n_pad, lk(self.act), lk(self.out_act),
+                                                  sa.data_ptr(), sb.data_ptr(), y.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return y[:, : self.n_output_dims]
 
     __call__ = forward

@@ -221,6 +221,14 @@ int32_t d3d_gemm_nt(const void* A_d, const void* W_d, void* C_d, const void* bia
 int32_t d3d_gemm_nt_tile(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
                          int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
                          int32_t tile, void* stream);
+/* tinycudann `Network(otype="CutlassMLP")` forward in one call (PRE-FF:221-243, 484, 488): n_hidden + 1
+ * bias-free layers y = act(x W^T), fp16 storage / fp32 accumulation, one d3d_gemm_nt launch per layer with the activation in
+ * the epilogue.  x (n_rows, n_in) f16; weights: HOST array of n_hidden + 1 device pointers, layer l row-major (out_l, in_l)
+ * with the last layer's rows zero-padded to n_out_padded (% 128; e.g. 769 -> 896); act / out_act: 0 none, 1 LeakyReLU(0.01);
+ * scratch_a/b (n_rows, n_neurons) f16 each; y (n_rows, n_out_padded) f16. */
+int32_t d3d_mlp768_forward(const void* x_d, int64_t n_rows, int32_t n_in, const void* const* weights, int32_t n_hidden,
+                           int32_t n_neurons, int32_t n_out_padded, int32_t act, int32_t out_act, void* scratch_a_d,
+                           void* scratch_b_d, void* y_d, void* stream);
 /* One KV-cache decode token through the whole Phi-3 stack (HF Phi3DecoderLayer x n_layers + final norm + lm_head under
  * `llava.generate`, VLN-POL:463), every launch issued from C++.  All pointers are device pointers except the per-layer pointer
  * ARRAYS, which are host arrays of device pointers.  gate_up weights in the per-16 interleaved row order of epilogue 6;

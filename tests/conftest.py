@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
     config.addinivalue_line("markers", "reference: needs /root/reference mounted (build container only)")
+    config.addinivalue_line("markers", "slow: full-size CPU oracle case (tens of seconds)")
 
 
 def pytest_collection_modifyitems(config, items):
