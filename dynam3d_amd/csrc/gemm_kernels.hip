@@ -805,8 +805,15 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
     // 0.132 / 0.306 ms for the 128x128 kernel and 0.148 / 0.330 ms unsplit); otherwise the finer 128x128 grid wins.
     if (M <= 16 && N % 32 == 0 && K % 32 == 0 && (epilogue == EPI_NONE || epilogue == EPI_RES || epilogue == EPI_SWIGLU || epilogue == EPI_BIAS))
         return d3d_gemm_nt_tile(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, dtype, epilogue, 16, stream);   // weight streaming
-    const int64_t rows256 = (int64_t)(M / TM) * TM;
-    const int64_t blocks256 = (rows256 / TM) * (N / TN);
+    // A partial last row of 256-tiles rides in the 256 launch when it does not add a round (the kernel clamps its loads and
+    // masks its stores): ViT qkv at M = 4616 is 228 tiles in one round, 41 us, against 216 tiles + a remainder launch, 52 us.
+    int64_t tm256 = M / TM;
+    if (M % TM && tm256 > 0 && N % TN == 0) {
+        const int64_t P = cu_count(), tn = N / TN;
+        if (((tm256 + 1) * tn + P - 1) / P == (tm256 * tn + P - 1) / P) tm256 += 1;
+    }
+    const int64_t rows256 = tm256 * TM < M ? tm256 * TM : M;
+    const int64_t blocks256 = tm256 * (N / TN);
     int tile = 128;
     if (N % TN == 0 && (blocks256 >= 768 || (blocks256 <= cu_count() && blocks256 * 4 >= cu_count() * 3))) {
         tile = 257;               // several rounds, or one nearly full round (ViT qkv at M = 4616: 216 tiles, 41.6 us against 46.3 us)
