@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--episodes-per-rank", type=int, default=8)
     ap.add_argument("--max-steps", type=int, default=50)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--stop-mod", type=int, default=7, help="an episode stops when its argmax token is divisible by this (huge = never: full-length episodes)")
     a = ap.parse_args()
     rank, local, world = DD.init_from_env()
     torch.cuda.set_device(local)
@@ -71,10 +72,14 @@ def main():
     cfg = PolicyConfig()
     net = Dynam3D_VLN(cfg, synth_policy_weights(cfg, a.seed, device=dev), device=dev, batch_size=a.episodes_per_rank, max_steps=a.max_steps + 1)
     t0 = time.time()
-    sums, n = run_rollout(net, a.episodes_per_rank, a.max_steps, seed=a.seed + 1000 * rank)      # seed + rank (VLN-TR:141)
+    sums, n = run_rollout(net, a.episodes_per_rank, a.max_steps, seed=a.seed + 1000 * rank, stop_token_mod=a.stop_mod)   # seed + rank (VLN-TR:141)
+    torch.cuda.synchronize()
     res = DD.gather_metrics(sums, n, device=dev)                                                # the ONE collective
     if rank == 0:
-        print(json.dumps(dict(world=world, episodes=res["episodes"], seconds=round(time.time() - t0, 2), metrics=res)))
+        dt = time.time() - t0
+        print(json.dumps(dict(world=world, episodes=res["episodes"], seconds=round(dt, 2),
+                              env_steps_per_s=round(res["steps_taken"] * res["episodes"] / dt, 1), metrics=res)))
+    DD.shutdown()
 
 
 if __name__ == "__main__":
