@@ -14,7 +14,8 @@
 //     what the S^T accumulators hold -- no cross-lane data movement between the two GEMMs.
 //   * O^T accumulators put 4 consecutive head-dim elements of one query in a lane: 8-byte packed stores.
 //   * K rows are XOR-swizzled on 16-byte chunks, V^T rows padded by 4 elements: conflict-free ds_read_b128 / ds_read_b64.
-//   * V is pre-transposed once per layer (k_transpose_v); K/V^T tiles are prefetched into registers one tile ahead.
+//   * V: staged row-major and transposed by the LDS read itself (ds_read_b64_tr_b16, template flag VTR; the default), or
+//     pre-transposed once per call into a workspace (k_transpose_v); K/V tiles are prefetched into registers one tile ahead.
 //   * softmax VALU diet (the loop is partly VALU-bound: 34 % VALU-active against 13 % MFMA-busy per SIMD at the ViT shape):
 //     three-input maxima, packed f32 fma / add for the exponent arguments and row sums, row reductions through
 //     v_permlane16/32_swap instead of ds_bpermute: -4.5 % kernel time, measured A/B with alternating libraries.
@@ -30,6 +31,7 @@ namespace {
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using float4v = __attribute__((ext_vector_type(4))) float;
+using v4s = __attribute__((ext_vector_type(4))) short;
 
 // Cross-lane reductions over the four 16-lane rows of a wave (the lanes that share one query column) in the VALU:
 // v_permlane16_swap exchanges the odd rows of vdst with the even rows of src, v_permlane32_swap the upper half of vdst
@@ -112,21 +114,27 @@ k_transpose_v(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ vt, int S
     }
 }
 
-template <bool BF16, int HD, bool CAUSAL>
+// VTR: V is staged ROW-major straight from the fused projection buffer and the A operand of O^T = V^T P^T is fetched with the
+// transposing LDS read of gfx950 (ds_read_b64_tr_b16: the 16 lanes of a group address one [4 keys][16 dims] block, 8 bytes each,
+// and lane j receives column j of it -- exactly "4 consecutive keys of one head-dim element").  No k_transpose_v pass, no V^T
+// workspace.  V rows are padded to an odd multiple of 32 bytes: the 8 rows a half-wave touches then fall into 8 different
+// 32-byte bank groups.
+template <bool BF16, int HD, bool CAUSAL, bool VTR>
 __global__ void __launch_bounds__(NT, 2)          // 2 waves/SIMD = 2 workgroups per CU: keep VGPR+AGPR <= 256
 k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, int Sp, uint16_t* __restrict__ out, int S, int H,
              int64_t row_stride /* elements between tokens */, int64_t batch_stride, int q_off, int k_off, float scale_log2e, int seq_len,
-             const int32_t* __restrict__ cu /* packed batch: (B+1) row offsets, or null */, int n_qblocks) {
+             const int32_t* __restrict__ cu /* packed batch: (B+1) row offsets, or null */, int n_qblocks, int v_off) {
     // K rows are padded to a power-of-two number of 16-byte chunks and XOR-swizzled (chunk ^= row & (KCH-1)): every
     // ds_read_b128 lane group (which mixes two k-groups, e.g. lanes {0-3,12-15,20-27}) then hits 16 distinct slots.
     constexpr int KCH = HD == 96 ? 16 : 8;   // chunk positions per LDS row
     constexpr int KST = KCH * 8;             // K row stride (elements): 256 B (hd 96) / 128 B (hd 64)
     constexpr int VST = BKV + 4;             // V^T row stride 136 B: dword stride 34 -> conflict-free 8-byte reads
+    constexpr int VSTR = HD + 16;            // VTR: row-major V rows, 224 B (hd 96) / 160 B (hd 64) = odd multiples of 32 B
     constexpr int DS = HD / 32;          // 32-deep steps over head_dim (QK^T)
     constexpr int DT = HD / 16;          // 16-wide head-dim tiles (PV)
     constexpr int CH = HD / 8;           // 16-byte chunks per row
     __shared__ __attribute__((aligned(16))) uint16_t Ks[BKV * KST];
-    __shared__ __attribute__((aligned(16))) uint16_t Vt[HD * VST];
+    __shared__ __attribute__((aligned(16))) uint16_t Vt[VTR ? BKV * VSTR : HD * VST];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
@@ -152,7 +160,7 @@ k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, 
     const int q0 = qb * BQ, qw = q0 + wave * 32;
     const uint16_t* Qp = base + (int64_t)(q_off + h) * HD;
     const uint16_t* Kp = base + (int64_t)(k_off + h) * HD;
-    const uint16_t* Vtp = vt + (((int64_t)b * H + h) * HD) * Sp;          // (hd, Sp) key-major
+    const uint16_t* Vtp = VTR ? base + (int64_t)(v_off + h) * HD : vt + (((int64_t)b * H + h) * HD) * Sp;   // token-major V / (hd, Sp) key-major V^T
 
     // Q fragments (B operand): lane holds Q[q = qw + qt*16 + fi][d = ks*32 + fg*8 .. +7]
     uint4 qf[2][DS];
@@ -175,7 +183,7 @@ k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, 
 
     // register-staged prefetch (issue-early / write-late): tile t+1 is loaded into VGPRs before tile t is computed and
     // written to LDS after it, so the global-load latency hides under the MFMA + softmax work of the current tile.
-    constexpr int NK = (BKV * CH) / NT, NV = (HD * 8) / NT;      // 3,3 (hd 96) or 2,2 (hd 64) 16-byte chunks per thread
+    constexpr int NK = (BKV * CH) / NT, NV = VTR ? NK : (HD * 8) / NT;      // 3,3 (hd 96) or 2,2 (hd 64) 16-byte chunks per thread
     static_assert(NK <= 3 && NV <= 3, "tile shape");
     // named scalars (not arrays: loop-carried uint4 arrays were left in scratch memory by the compiler)
     uint4 kr0, kr1, kr2 = make_uint4(0, 0, 0, 0), vr0, vr1, vr2 = make_uint4(0, 0, 0, 0);
@@ -186,8 +194,14 @@ k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, 
         return *reinterpret_cast<const uint4*>(Kp + (int64_t)kr * row_stride + (c % CH) * 8);
     };
     auto ld_v = [&](int key0_, int i) -> uint4 {
-        const int c = tid + i * NT;                                                                // (d, 8-key chunk)
-        return *reinterpret_cast<const uint4*>(Vtp + (int64_t)(c >> 3) * Sp + key0_ + (c & 7) * 8);
+        const int c = tid + i * NT;
+        if constexpr (VTR) {                                                                       // (key, 8-dim chunk), like K
+            int kr = key0_ + c / CH;
+            kr = kr < S ? kr : S - 1;
+            return *reinterpret_cast<const uint4*>(Vtp + (int64_t)kr * row_stride + (c % CH) * 8);
+        } else {                                                                                   // (d, 8-key chunk)
+            return *reinterpret_cast<const uint4*>(Vtp + (int64_t)(c >> 3) * Sp + key0_ + (c & 7) * 8);
+        }
     };
     auto st_k = [&](int i, const uint4& v) {
         const int c = tid + i * NT;
@@ -196,9 +210,13 @@ k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, 
     };
     auto st_v = [&](int i, const uint4& v) {
         const int c = tid + i * NT;
-        uint16_t* d = Vt + (c >> 3) * VST + (c & 7) * 8;                                          // V^T rows of 64 keys (8-byte aligned)
-        *reinterpret_cast<uint2*>(d) = make_uint2(v.x, v.y);
-        *reinterpret_cast<uint2*>(d + 4) = make_uint2(v.z, v.w);
+        if constexpr (VTR) {
+            *reinterpret_cast<uint4*>(Vt + (c / CH) * VSTR + (c % CH) * 8) = v;                    // row-major V rows (16-byte aligned)
+        } else {
+            uint16_t* d = Vt + (c >> 3) * VST + (c & 7) * 8;                                      // V^T rows of 64 keys (8-byte aligned)
+            *reinterpret_cast<uint2*>(d) = make_uint2(v.x, v.y);
+            *reinterpret_cast<uint2*>(d + 4) = make_uint2(v.z, v.w);
+        }
     };
 #define FA_LOAD_TILE(T)                                       \
     {                                                         \
@@ -311,10 +329,22 @@ k_flash_attn(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, 
         for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
-                const uint16_t* vrow = Vt + (dt * 16 + fi) * VST + kp * 32 + fg * 4;
-                const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
-                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                uint4 vf;
+                if constexpr (VTR) {
+                    // lane (fg, fi) addresses key 4*fg + fi/4 of the 16-key tile, dims (fi%4)*4.. of this 16-dim tile; it gets
+                    // back dim fi for keys 4*fg..4*fg+3: slots 0-3 from the even key tile, 4-7 from the odd one
+                    using lds_v4s = __attribute__((address_space(3))) v4s;
+                    const uint16_t* vblk = Vt + (kp * 32 + fg * 4 + (fi >> 2)) * VSTR + dt * 16 + (fi & 3) * 4;
+                    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)vblk);
+                    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(vblk + 16 * VSTR));
+                    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    vf = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                } else {
+                    const uint16_t* vrow = Vt + (dt * 16 + fi) * VST + kp * 32 + fg * 4;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+                    vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) oacc[qt][dt] = mfma16<BF16>(vf, pf[qt][kp], oacc[qt][dt]);
             }
@@ -502,7 +532,8 @@ extern "C" {
 // Self-attention over a fused projection buffer.  qkv: (B, S, Htot, hd) 16-bit with q heads at [q_off, q_off+H), k heads
 // at [k_off, ..), v heads at [v_off, ..); token stride = row_stride elements, batch stride = batch_stride elements.
 // out: (B, S, H, hd) contiguous.  seq_len = number of valid keys (<= S).  dtype 0 = bf16, 1 = fp16; hd in {64, 96}.
-// vt_scratch: caller-provided (B, H, hd, Sp) 16-bit workspace, Sp = S rounded up to 64 (the pre-transposed V).
+// vt_scratch: NULL (V is staged row-major and transposed by ds_read_b64_tr_b16 inside the kernel), or a caller-provided
+// (B, H, hd, Sp) 16-bit workspace, Sp = S rounded up to 64, for the variant that pre-transposes V once per call.
 // cu_seqlens (optional, device, B+1 ints): PACKED batch -- sequence b occupies rows [cu[b], cu[b+1]) of qkv/out, S is then the
 // longest sequence (grid size) and batch_stride / seq_len are ignored.
 int32_t d3d_flash_attention(const void* qkv, void* out, void* vt_scratch, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride,
@@ -520,11 +551,22 @@ int32_t d3d_flash_attention(const void* qkv, void* out, void* vt_scratch, int32_
     uint16_t* o = (uint16_t*)out;
     uint16_t* vt = (uint16_t*)vt_scratch;
     dim3 tg(Sp / 64, H, B);
-    if (head_dim == 96) hipLaunchKernelGGL(k_transpose_v<96>, tg, dim3(256), 0, s, q, vt, S, Sp, H, row_stride, batch_stride, v_off, cu_seqlens);
-    else hipLaunchKernelGGL(k_transpose_v<64>, tg, dim3(256), 0, s, q, vt, S, Sp, H, row_stride, batch_stride, v_off, cu_seqlens);
+    const bool vtr = vt == nullptr;      // no workspace: V is read row-major and transposed by the LDS read itself
+    if (!vtr) {
+        if (head_dim == 96) hipLaunchKernelGGL(k_transpose_v<96>, tg, dim3(256), 0, s, q, vt, S, Sp, H, row_stride, batch_stride, v_off, cu_seqlens);
+        else hipLaunchKernelGGL(k_transpose_v<64>, tg, dim3(256), 0, s, q, vt, S, Sp, H, row_stride, batch_stride, v_off, cu_seqlens);
+    }
     const int nqb = (S + BQ - 1) / BQ;
     dim3 grid(causal ? (nqb + 1) / 2 : nqb, H, B), block(NT);            // causal: one workgroup per PAIR of query blocks
-#define D3D_FA(BF, HDV, CA) hipLaunchKernelGGL((k_flash_attn<BF, HDV, CA>), grid, block, 0, s, q, vt, Sp, o, S, H, row_stride, batch_stride, q_off, k_off, sl2, seq_len, cu_seqlens, nqb)
+#define D3D_FA(BF, HDV, CA)                                                                                                              \
+    do {                                                                                                                                \
+        if (vtr)                                                                                                                        \
+            hipLaunchKernelGGL((k_flash_attn<BF, HDV, CA, true>), grid, block, 0, s, q, vt, Sp, o, S, H, row_stride, batch_stride, q_off, \
+                               k_off, sl2, seq_len, cu_seqlens, nqb, v_off);                                                            \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((k_flash_attn<BF, HDV, CA, false>), grid, block, 0, s, q, vt, Sp, o, S, H, row_stride, batch_stride,      \
+                               q_off, k_off, sl2, seq_len, cu_seqlens, nqb, v_off);                                                     \
+    } while (0)
     if (dtype == 0) {
         if (head_dim == 96) { if (causal) D3D_FA(true, 96, true); else D3D_FA(true, 96, false); }
         else { if (causal) D3D_FA(true, 64, true); else D3D_FA(true, 64, false); }

@@ -179,11 +179,13 @@ class HipDense:
     def attention_ok(qkv, hd):
         return qkv.dtype in (torch.bfloat16, torch.float16) and hd in (64, 96) and qkv.is_contiguous()
 
+    V_TR = True    # True: V transposed by the LDS read inside the kernel (no workspace); False: pre-transposed V^T workspace (A/B, tests)
+
     def attention_qkv(self, qkv, n_heads, causal, seq_len=None):
         """qkv (B,S,3H,hd) contiguous fused projection -> (B,S,H,hd): flash attention straight off the projection buffer."""
         B, S, Ht, hd = qkv.shape
         out = torch.empty((B, S, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
-        vt = torch.empty((B, n_heads, hd, (S + 63) // 64 * 64), dtype=qkv.dtype, device=qkv.device)     # pre-transposed V workspace
+        vt = None if self.V_TR else torch.empty((B, n_heads, hd, (S + 63) // 64 * 64), dtype=qkv.dtype, device=qkv.device)
         _lib.check(self.lib.d3d_flash_attention(_p(qkv), _p(out), _p(vt), B, S, n_heads, hd, Ht * hd, S * Ht * hd, 0, n_heads, 2 * n_heads,
                                                 1 if causal else 0, S if seq_len is None else seq_len, None,
                                                 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
@@ -199,7 +201,7 @@ class HipDense:
             out = torch.empty((T, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
             if n_valid < T:
                 out[n_valid:].zero_()
-        vt = torch.empty((n_seq, n_heads, hd, (max_len + 63) // 64 * 64), dtype=qkv.dtype, device=qkv.device)
+        vt = None if self.V_TR else torch.empty((n_seq, n_heads, hd, (max_len + 63) // 64 * 64), dtype=qkv.dtype, device=qkv.device)
         _lib.check(self.lib.d3d_flash_attention(_p(qkv), _p(out), _p(vt), n_seq, max_len, n_heads, hd, Ht * hd, 0, 0, n_heads, 2 * n_heads,
                                                 1 if causal else 0, max_len, _p(cu_seqlens), 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
         return out

@@ -183,9 +183,12 @@ def test_set_attention_varlen(hd):
             assert float(cls[off[g] + 1:off[g + 1]].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("v_tr", [True, False])
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 4e-3), (torch.float16, 6e-4)])
-def test_flash_attention_vs_fp32_reference(hd, dt, tol):
-    """d3d_flash_attention (head_dim 64/96, causal/full, ragged S, masked tail) vs float32 SDPA on the same 16-bit inputs."""
+def test_flash_attention_vs_fp32_reference(hd, dt, tol, v_tr, monkeypatch):
+    """d3d_flash_attention (head_dim 64/96, causal/full, ragged S, masked tail) vs float32 SDPA on the same 16-bit inputs.
+    v_tr: V transposed by ds_read_b64_tr_b16 inside the kernel (the default) / the pre-transposed V^T workspace variant."""
+    monkeypatch.setattr(type(hd), "V_TR", v_tr)
     torch.manual_seed(4)
     for (B, H, S, d, causal) in [(2, 3, 577, 64, False), (2, 4, 900, 96, True), (1, 2, 130, 96, True), (3, 2, 64, 64, True), (1, 1, 1, 96, True), (2, 2, 333, 96, False)]:
         qkv = (torch.randn(B, S, 3 * H, d, device="cuda") * 1.5).to(dt)
@@ -204,12 +207,14 @@ def test_flash_attention_vs_fp32_reference(hd, dt, tol):
     assert rel(hd.attention_qkv(qkv, H, True).float(), ref) < tol
 
 
+@pytest.mark.parametrize("v_tr", [True, False])
 @pytest.mark.parametrize("causal", [True, False])
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 6e-3), (torch.float16, 1e-3)])
-def test_flash_attention_packed_ragged(hd, dt, tol, causal):
+def test_flash_attention_packed_ragged(hd, dt, tol, causal, v_tr, monkeypatch):
     """Packed variable-length batch (cu_seqlens): sequences of 1 token, below / at / just above a 128-row query block and a
     64-key tile, odd and even block counts (the causal kernel pairs the longest block of a sequence with its shortest), padding
     rows after the last sequence.  Reference: fp32 softmax attention per sequence.  Tolerance = 16-bit output rounding + 16-bit P."""
+    monkeypatch.setattr(type(hd), "V_TR", v_tr)
     torch.manual_seed(5)
     H, d = 4, 96
     lens = [1, 63, 128, 129, 200, 385, 640, 705]

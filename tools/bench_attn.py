@@ -19,12 +19,15 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dynam3d_amd.hip_dense import HipDense
 hd_ = HipDense()
-for (B,H,S,hd,causal,dt) in [(8,32,900,96,True,torch.bfloat16),(8,16,577,64,False,torch.float16),(8,16,577,64,False,torch.bfloat16),(2,4,200,96,True,torch.bfloat16),(8,32,900,96,False,torch.bfloat16)]:
-    qkv = torch.randn(B,S,3*H,hd,device="cuda").to(dt)
-    q,k,v = qkv[:,:,:H],qkv[:,:,H:2*H],qkv[:,:,2*H:]
-    ref = F.scaled_dot_product_attention(q.transpose(1,2).float(),k.transpose(1,2).float(),v.transpose(1,2).float(),is_causal=causal).transpose(1,2)
-    got = hd_.attention_qkv(qkv, H, causal).float()
-    err = float((got-ref).norm()/ref.norm())
-    fl = 4*B*H*S*S*hd/(2 if causal else 1)
-    t = timeit(lambda: hd_.attention_qkv(qkv, H, causal))
-    print(f"own flash B{B} H{H} S{S} hd{hd} causal={causal} {dt}: {t*1e3:.1f} us ({fl/t/1e9:.0f} TF/s) relerr {err:.2e}")
+for vtr in (False, True, False, True):
+  HipDense.V_TR = vtr
+  print("== V_TR", vtr)
+  for (B,H,S,hd,causal,dt) in [(8,32,900,96,True,torch.bfloat16),(8,16,577,64,False,torch.float16),(8,16,577,64,False,torch.bfloat16),(2,4,200,96,True,torch.bfloat16),(8,32,900,96,False,torch.bfloat16)]:
+      qkv = torch.randn(B,S,3*H,hd,device="cuda").to(dt)
+      q,k,v = qkv[:,:,:H],qkv[:,:,H:2*H],qkv[:,:,2*H:]
+      ref = F.scaled_dot_product_attention(q.transpose(1,2).float(),k.transpose(1,2).float(),v.transpose(1,2).float(),is_causal=causal).transpose(1,2)
+      got = hd_.attention_qkv(qkv, H, causal).float()
+      err = float((got-ref).norm()/ref.norm())
+      fl = 4*B*H*S*S*hd/(2 if causal else 1)
+      t = timeit(lambda: hd_.attention_qkv(qkv, H, causal))
+      print(f"own flash B{B} H{H} S{S} hd{hd} causal={causal} {dt}: {t*1e3:.1f} us ({fl/t/1e9:.0f} TF/s) relerr {err:.2e}")
