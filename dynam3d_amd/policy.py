@@ -119,6 +119,11 @@ class Dynam3D_VLN:
         self.last_lengths = None
         self._lowp_w = {}
 
+    def _cull_stream(self):
+        if getattr(self, "_cull", None) is None:
+            self._cull = torch.cuda.Stream(device=self.device)
+        return self._cull
+
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -172,20 +177,35 @@ class Dynam3D_VLN:
         depth = observations["depth"].to(self.device, torch.float32)
         depth24 = self._depth24(depth, V, depth_scale)                                        # (B,V,576) metres
         pixels = preprocess_rgb(rgb)                                                          # shared by both towers
-        _, grid = self.rgb_encoder.forward(pixels)                                            # (B*V,576,768) fp16, stays on device
-        # The llava vision tower only needs `pixels`: run it on a second HIP stream underneath the 3D-token
-        # update, whose host round trips (hit lists, merge decisions, Ni/Nz) would otherwise idle the GPU.
-        side = None
-        if self.device.type == "cuda":
+        cuda = self.device.type == "cuda"
+        dfull = None
+        if delete_old_features:
+            dfull = self.ops.preprocess_depth(depth[..., 0], *depth_scale).view(B, V, depth.shape[1], depth.shape[2])
+        if cuda:
             main = torch.cuda.current_stream()
+            ready = main.record_event()                                                       # depth / pools ready, CLIP not yet queued
+        _, grid = self.rgb_encoder.forward(pixels)                                            # (B*V,576,768) fp16, stays on device
+        # The frustum cull needs the depth and the stored rows, not the CLIP features: it runs -- with its host round trip for the
+        # hit lists -- on a third stream UNDER the CLIP tower, which the host has only queued at this point.
+        if delete_old_features:
+            if cuda:
+                cull = self._cull_stream()
+                cull.wait_event(ready)
+                with torch.cuda.stream(cull):
+                    ff.delete_old_features_from_camera_frustum(dfull, agent_positions, agent_heading_angles, num_of_views=V)
+                dfull.record_stream(cull)
+                main.wait_stream(cull)
+            else:
+                ff.delete_old_features_from_camera_frustum(dfull, agent_positions, agent_heading_angles, num_of_views=V)
+        # The llava vision tower only needs `pixels`: run it on a second HIP stream underneath the 3D-token
+        # update, whose host round trips (merge decisions, Ni/Nz) would otherwise idle the GPU.
+        side = None
+        if cuda:
             side = self._side_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 patch_feat = self.llava_vision.forward(pixels)
             pixels.record_stream(side)
-        if delete_old_features:
-            dfull = self.ops.preprocess_depth(depth[..., 0], *depth_scale).view(B, V, depth.shape[1], depth.shape[2])
-            ff.delete_old_features_from_camera_frustum(dfull, agent_positions, agent_heading_angles, num_of_views=V)
         ff.update_feature_fields(depth24, grid.view(B, V, ff.P, -1), rgb, agent_positions, agent_heading_angles, num_of_views=V,
                                  patch_segm=patch_segm)
         with TIMER.range("prefix.query"):
