@@ -155,6 +155,12 @@ class Dynam3D_VLN:
             return D.linear(h.reshape(-1, h.shape[-1]).to(dt), w3, b3).view(*h.shape[:-1], -1)
         return F.linear(h, w[name + ".3.weight"], w[name + ".3.bias"])
 
+    def _patch_position_tokens(self, depth24, B, V):
+        """patch_position_embedding over [x, y, z, sin d, cos d, scale] of every patch (VLN-POL:432-433); needs the depth only."""
+        rel_x, rel_y, rel_z, direction, scale = self.feature_fields.get_patch_3d_info(depth24.reshape(B * V, -1))
+        info = torch.cat([rel_x, rel_y, rel_z, torch.sin(direction), torch.cos(direction), scale], dim=-1)
+        return self._mlp(info, "patch_position_embedding", lowp=True)
+
     def _depth24(self, depth, V, depth_scale):
         B = depth.shape[0]
         a = self.feature_fields.args
@@ -178,7 +184,7 @@ class Dynam3D_VLN:
         depth24 = self._depth24(depth, V, depth_scale)                                        # (B,V,576) metres
         pixels = preprocess_rgb(rgb)                                                          # shared by both towers
         cuda = self.device.type == "cuda"
-        dfull = None
+        dfull = patch_pos = None
         if delete_old_features:
             dfull = self.ops.preprocess_depth(depth[..., 0], *depth_scale).view(B, V, depth.shape[1], depth.shape[2])
         if cuda:
@@ -193,8 +199,11 @@ class Dynam3D_VLN:
                 cull.wait_event(ready)
                 with torch.cuda.stream(cull):
                     ff.delete_old_features_from_camera_frustum(dfull, agent_positions, agent_heading_angles, num_of_views=V)
+                    patch_pos = self._patch_position_tokens(depth24, B, V)                   # depth only: also under the CLIP tower
                 dfull.record_stream(cull)
+                depth24.record_stream(cull)
                 main.wait_stream(cull)
+                patch_pos.record_stream(main)
             else:
                 ff.delete_old_features_from_camera_frustum(dfull, agent_positions, agent_heading_angles, num_of_views=V)
         # The llava vision tower only needs `pixels`: run it on a second HIP stream underneath the 3D-token
@@ -211,15 +220,14 @@ class Dynam3D_VLN:
         with TIMER.range("prefix.query"):
             env = ff.get_environment_features(agent_positions, agent_heading_angles)
         with TIMER.range("prefix.mlps"):
-            rel_x, rel_y, rel_z, direction, scale = ff.get_patch_3d_info(depth24.reshape(B * V, -1))
-            info = torch.cat([rel_x, rel_y, rel_z, torch.sin(direction), torch.cos(direction), scale], dim=-1)   # VLN-POL:432
-            patch_pos = self._mlp(info, "patch_position_embedding", lowp=True)                    # (B*V,576,3072)
+            if patch_pos is None:
+                patch_pos = self._patch_position_tokens(depth24, B, V)                            # (B*V,576,3072)
             ni = [int(t.shape[0]) for t in env["batch_instance_fts"]]
             nz = [int(t.shape[0]) for t in env["batch_zone_fts"]]
             ifts, irel = torch.cat(env["batch_instance_fts"]), torch.cat(env["batch_instance_relative_position"])
             zfts, zrel = torch.cat(env["batch_zone_fts"]), torch.cat(env["batch_zone_relative_position"])
-            inst_tok = self._mlp(torch.cat([ifts, self._mlp(irel, "instance_position_embedding")], -1), "instance_projector")   # VLN-POL:434
-            zone_tok = self._mlp(torch.cat([zfts, self._mlp(zrel, "zone_position_embedding")], -1), "zone_projector")           # VLN-POL:435
+            inst_tok = self._mlp(torch.cat([ifts, self._mlp(irel, "instance_position_embedding")], -1), "instance_projector", lowp=True)   # VLN-POL:434
+            zone_tok = self._mlp(torch.cat([zfts, self._mlp(zrel, "zone_position_embedding")], -1), "zone_projector", lowp=True)           # VLN-POL:435
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             patch_feat.record_stream(torch.cuda.current_stream())
