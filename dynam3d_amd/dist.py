@@ -18,8 +18,10 @@ def init_from_env(backend: Optional[str] = None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set by torch.distributed.run.  Returns (rank, local_rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("D3D_SHARE_DEVICE0") == "1":
+        local = 0          # test hook: several ranks on ONE GPU (with D3D_DIST_BACKEND=gloo; RCCL refuses duplicate devices)
     if world > 1 and not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("D3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, init_method="env://")

@@ -148,3 +148,23 @@ def test_policy_forward_generates_text_with_kv_cache():
         assert len(acts) == 2
     after = net.feature_fields.history_actions
     assert all(len(a) == len(b) for a, b in zip(after, before)) and all(a[-1] == t + "\n" for a, t in zip(after, texts))
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """The driver's N > 1 launch of bench.py (torch.distributed.run, one rank per GPU) exercised on a ONE-GPU box: both ranks on
+    cuda:0 over gloo (D3D_SHARE_DEVICE0 / D3D_DIST_BACKEND test hooks; RCCL refuses duplicate devices).  Checks the barrier /
+    max-over-ranks timing / rank-0 JSON line path, not performance."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, D3D_SHARE_DEVICE0="1", D3D_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--warm-steps", "1"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 8 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-2 * d["value"]   # whole-job aggregate
