@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O2 -o tools/probe/tr_probe tools/probe/tr_probe.hip ; run on the GPU box: tools/probe/tr_probe
 // Probe of ds_read_b64_tr_b16 semantics on gfx950: LDS holds value = row*256 + col (16-bit), 64 rows x 64 cols row-major.
 // Lane l (group g = l>>4, j = l&15) reads at row = 4*g + (j>>2), col = (j&3)*4  -> prints the 4 values each lane receives.
 #include <hip/hip_runtime.h>
