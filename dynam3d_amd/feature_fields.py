@@ -218,6 +218,20 @@ class Feature_Fields:
         new.inst_pos, new.inst_fts, new.tree_pos, new.zone_pos, new.zone_fts = old.inst_pos, old.inst_fts, old.tree_pos, old.zone_pos, old.zone_fts
         self.pools = new
 
+    def _grow_slots(self, which: str, need: int):
+        """The reference's instance / zone stores grow without bound (torch.cat, VLN-FF:645-648, 737); these pools double."""
+        p = self.pools
+        names = ("inst_pos", "inst_fts", "tree_pos") if which == "inst" else ("zone_pos", "zone_fts")
+        cap = getattr(p, names[0]).shape[1]
+        if need <= cap:
+            return
+        new_cap = max(need, 2 * cap)
+        for n in names:
+            old = getattr(p, n)
+            new = torch.zeros((old.shape[0], new_cap) + tuple(old.shape[2:]), dtype=old.dtype, device=old.device)
+            new[:, :cap] = old
+            setattr(p, n, new)
+
     def _snapshot_tree(self):
         # kd-tree rebuild (VLN-FF:396, 815): the tree owns a COPY of the instance centres
         self.pools.tree_pos.copy_(self.pools.inst_pos)
@@ -408,8 +422,7 @@ class Feature_Fields:
                     m_tok_slot.append(np.full(len(rows), self.slots[e], np.int32)); m_tok_row.append(rows)
                     m_lens.append(len(rows)); m_slot.append(self.slots[e]); m_inst.append(int(inst)); m_env.append(j_)
             self.last_debug.append(dbg)
-            if max(st.count(e, st.SLOTS) for e in envs) > pools.m_cap:
-                raise RuntimeError("instance pool capacity exceeded (raise m_cap)")
+            self._grow_slots("inst", max(st.count(e, st.SLOTS) for e in envs))
             if new_r:                                                        # VLN-FF:643-648
                 s, r, src = self._i32(new_s), self._i32(new_r), self._i32(new_src)
                 ops.scatter_rows(pools.inst_pos, s, r, centroid, src)
@@ -433,8 +446,7 @@ class Feature_Fields:
                     mem = zmem[zoff[t]:zoff[t + 1]]
                     z_tok_slot.append(np.full(len(mem), self.slots[e], np.int32)); z_tok_inst.append(mem)
                     z_lens.append(len(mem)); z_mode.append(int(zmode[t])); z_slot.append(self.slots[e]); z_row.append(int(zrow[t]))
-            if max(st.count(e, st.ZROWS) for e in envs) > pools.z_cap:
-                raise RuntimeError("zone pool capacity exceeded (raise z_cap)")
+            self._grow_slots("zone", max(st.count(e, st.ZROWS) for e in envs))
             if z_lens:
                 ts = self._i32(np.concatenate(z_tok_slot) if sum(z_lens) else np.zeros(0, np.int32))
                 ti = self._i32(np.concatenate(z_tok_inst) if sum(z_lens) else np.zeros(0, np.int32))

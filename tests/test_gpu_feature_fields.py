@@ -17,6 +17,13 @@ def test_feature_fields_trajectory_parity(name):
     assert ff.pools.rows_fts.is_cuda
 
 
+def test_row_pools_grow_mid_episode():
+    """Row pools sized for one step: they are reallocated (and copied on the device) during the episode; golden parity holds."""
+    from dynam3d_amd.ops import HipOps
+    ff = run_case("walk", HipOps(), "cuda", max_steps=1, m_cap=8, z_cap=2)       # instance / zone pools double as well
+    assert ff.pools.n_cap >= 7 * 576 and ff.pools.m_cap > 8 and ff.pools.z_cap > 2
+
+
 def test_pop_keeps_remaining_envs_consistent():
     import numpy as np
     from dynam3d_amd.feature_fields import Feature_Fields
