@@ -22,6 +22,7 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <unordered_map>
@@ -821,6 +822,22 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
         int dp_tiles, splits;
         split_plan((int)blocks256, K / BK, &dp_tiles, &splits);
         if (splits >= 3) tile = 258;
+    }
+    // A half-empty last round of a many-round 256-tile grid goes to the 128 x 128 kernel when it is made of whole rows of tiles:
+    // gate_up at M = 6656 is 26 x 64 = 6.5 rounds -- 24 row tiles fill 6 rounds exactly, the last 512 rows are 4 x 128 = 512
+    // workgroups of the 128-kernel = one round of ITS 512 slots (49 us instead of a 76 us round that idles half the CUs).
+    static const bool tail128 = [] { const char* e = getenv("D3D_GEMM_TAIL128"); return !(e && e[0] == '0'); }();
+    if (tile == 257 && tail128 && rows256 == M && M % TM == 0) {
+        const int64_t P = cu_count(), tn = N / TN, tiles = tm256 * tn, R = tiles % P;
+        if (R > 0 && R * 2 <= P && R % tn == 0 && tm256 > R / tn) {
+            const int64_t m1 = (tm256 - R / tn) * TM;
+            int32_t rc = d3d_gemm_nt_tile(A, W, C, bias, residual, (int32_t)m1, N, K, lda, ldw, ldc, dtype, epilogue, 257, stream);
+            if (rc != D3D_OK) return rc;
+            const char* a8 = (const char*)A + m1 * lda * 2;
+            char* c8 = (char*)C + m1 * ldc * 2;
+            const char* r8 = residual ? (const char*)residual + m1 * ldc * 2 : nullptr;
+            return d3d_gemm_nt_tile(a8, W, c8, bias, r8, (int32_t)(M - m1), N, K, lda, ldw, ldc, dtype, epilogue, 128, stream);
+        }
     }
     if (tile != 128) {
         int32_t rc = d3d_gemm_nt_tile(A, W, C, bias, residual, (int32_t)rows256, N, K, lda, ldw, ldc, dtype, epilogue, tile, stream);
