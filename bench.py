@@ -174,7 +174,7 @@ def main():
                        "instances_per_env": st.count(0, st.LIVE), "clip_dtype": str(cfg.clip_dtype), "llm_dtype": str(cfg.llava_dtype),
                        "token_builder_dtype": "float32", "parallelism": f"episode-parallel x{a.gpus} (no data-path collective)",
                        "dense_backend": dict(D.BACKEND)},
-            "roofline": {"bound": "mfma", "kernel": "phi3.gate_up_proj GEMM + fused SwiGLU (sum(S_b) x 3072 x 16384, bf16)", "gemm_rows_launched": rows_gemm, "real_tokens": sum(lengths_seen[-1]), "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": "phi3.gate_up_proj GEMM + fused SwiGLU (sum(S_b) x 3072 x 16384, bf16): k_gemm_nt_256<bf16,SwiGLU> on the full rounds (+ k_gemm_nt<bf16,SwiGLU> on the last rows when the last round is at most half full); avg_launch_ms covers the whole projection", "gemm_rows_launched": rows_gemm, "real_tokens": sum(lengths_seen[-1]), "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "launches_timed": n_gu, "avg_launch_ms": round(ms_gu, 4),
                          "step_total_tflop": round(fl["total"] / 1e12, 2), "step_frac_of_peak": round(fl["total"] / (ms * 1e-3) / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4),
