@@ -278,7 +278,8 @@ int32_t d3d_swiglu(const void* gate_up_d, void* out_d, int64_t rows, int32_t I, 
 /* fused (flash) self-attention forward over a fused QKV projection buffer (clip/model.py:171-183 MultiheadAttention,
  * HF CLIP / Phi-3 attention): qkv (B,S,Htot,hd) 16-bit, q/k/v heads start at q_off/k_off/v_off; strides in elements;
  * out (B,S,H,hd); hd in {64,96}; keys >= seq_len are masked; causal = lower-triangular. */
-int32_t d3d_flash_attention(const void* qkv_d, void* out_d, void* vt_scratch_d /* (B,H,hd,ceil64(S)) 16-bit */, int32_t B, int32_t S, int32_t H,
+int32_t d3d_flash_attention(const void* qkv_d, void* out_d, void* vt_scratch_d /* NULL: V transposed by the LDS read inside the kernel (default); or a (B,H,hd,ceil64(S)) 16-bit workspace for the pre-transposing variant */,
+                            int32_t B, int32_t S, int32_t H,
                             int32_t head_dim, int64_t row_stride,
                             int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
                             const int32_t* cu_seqlens_d /* optional (B+1): packed variable-length batch */, int32_t dtype, void* stream);
