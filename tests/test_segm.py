@@ -54,3 +54,31 @@ def test_patch_segm_kernel_matches_reference_golden():
     for i, s in enumerate(sets):
         ref = G.patch_segm_from_masks(s)
         assert np.array_equal(segm[i].cpu().numpy(), ref) and int(n_seg[i]) == int(ref.max()) + 1
+
+
+def test_feature_fields_uses_configured_segmenter():
+    """`update_feature_fields(..., batch_image)` without an explicit patch_segm goes through `get_patch_segm` (VLN-FF:504-506) ->
+    the configured MaskSegmenter; the result must equal the run that was handed the same labels directly."""
+    from dynam3d_amd.feature_fields import Feature_Fields
+    from dynam3d_amd.segm import MaskSegmenter
+    from dynam3d_amd.weights import ff_param_spec, synth_state_dict
+    from tests.cpu_ops import CpuOps
+    from tests.golden_io import TRAJ_CASES, traj_inputs
+    ops = CpuOps()
+    sd = synth_state_dict(ff_param_spec(), seed=0)
+    inp = next(iter(traj_inputs(dict(TRAJ_CASES["walk"], steps=1))))
+    B = len(inp["positions"])
+    segm = inp["patch_segm"].reshape(B, 24, 24)
+
+    def masks_of(img_index):                                       # one {0,1} mask per label, at 48x48 (nearest-resized back to 24x24)
+        lab = np.kron(segm[img_index], np.ones((2, 2), np.int64))
+        return np.stack([(lab == k).astype(np.float32) for k in range(int(lab.max()) + 1)])
+
+    a = Feature_Fields(B, "cpu", sd, ops=ops, segmenter=MaskSegmenter(masks_of, ops, device="cpu"))
+    b = Feature_Fields(B, "cpu", sd, ops=ops)
+    for ff, kw in ((a, dict(batch_image=list(range(B)))), (b, dict(patch_segm=inp["patch_segm"]))):
+        ff.initialize_camera_setting(90.0, 90.0)
+        ff.update_feature_fields(inp["depth24"], inp["grid"], batch_position=inp["positions"], batch_heading=inp["headings"], **kw)
+    for e in range(B):
+        ea, eb = a.export_env(e), b.export_env(e)
+        assert ea["owner"] == eb["owner"] and np.array_equal(ea["ifts"], eb["ifts"]) and np.array_equal(ea["ipos"], eb["ipos"])
