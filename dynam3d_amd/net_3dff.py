@@ -40,6 +40,9 @@ class Net_3DFF:
     def __init__(self, vit: VitConfig, weights: Dict[str, torch.Tensor], device="cuda", batch_size: int = 1, ops=None,
                  clip_dtype=torch.float16, segmenter=None, max_steps: int = 16, depth_scale=(0.0, 10.0)):
         self.device = torch.device(device)
+        if self.device.type == "cuda":
+            from . import dense_ops as D
+            D.enable_hip_kernels(["all"])                                # the CLIP tower on the hand-written HIP kernels
         ff_sd = {k: weights[k] for k, _ in ff_param_spec(768)}
         self.feature_fields = Feature_Fields(batch_size, device, ff_sd, ops=ops, segmenter=segmenter, max_steps=max_steps,
                                              max_views=len(VIEW_IDS), variant="pretrain")

@@ -87,6 +87,8 @@ class PolicyConfig:
     llava_dtype: torch.dtype = torch.bfloat16    # reference: torch_dtype=torch.bfloat16 (VLN-POL:125)
     depth_quirk: bool = False                    # True reproduces `observations['depth'][b][i]` row indexing
     compat: str = "reference"
+    hip_dense: bool = True                       # on a GPU the towers run on the hand-written HIP kernels (dense_ops.enable_hip_kernels);
+                                                 # False keeps whatever dense_ops.BACKEND says (PyTorch-ROCm libraries by default)
 
 
 def synth_policy_weights(cfg: PolicyConfig, seed: int = 0, device: str = "cpu") -> Dict[str, torch.Tensor]:
@@ -107,6 +109,8 @@ class Dynam3D_VLN:
     def __init__(self, cfg: PolicyConfig = PolicyConfig(), weights: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0,
                  device="cuda", batch_size: int = 1, ops=None, tokenizer=None, segmenter=None, max_steps: int = 64):
         self.cfg, self.device = cfg, torch.device(device)
+        if self.device.type == "cuda" and cfg.hip_dense:
+            D.enable_hip_kernels(["all"])             # before the towers are built: they lay their weights out for these kernels
         sd = weights if weights is not None else synth_policy_weights(cfg, seed)
         ff_sd = {k: sd[k] for k, _ in ff_param_spec(768)}
         self.feature_fields = Feature_Fields(batch_size, device, ff_sd, compat=cfg.compat, ops=ops, segmenter=segmenter, max_steps=max_steps)
