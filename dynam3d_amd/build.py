@@ -20,6 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_SOURCES = [
     ("geometry_kernels.hip", ["-ffp-contract=off"]),
     ("dense_kernels.hip", ["-ffp-contract=fast"]),
+    ("tower_kernels.hip", ["-ffp-contract=off"]),
     ("gemm_kernels.hip", ["-ffp-contract=fast"]),
     ("attn_kernels.hip", ["-ffp-contract=fast"]),
     ("render_kernels.hip", ["-ffp-contract=off"]),

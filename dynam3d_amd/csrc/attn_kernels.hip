@@ -408,8 +408,10 @@ k_decode_attn(const uint16_t* __restrict__ qkv_new /* (B, 3H, HD): this step's r
         uint16_t kr1, kr2;
         if (cos_t) {
             const float c = cos_t[(int64_t)pos[b] * HALF + tid], sn = sin_t[(int64_t)pos[b] * HALF + tid];
-            const uint32_t qp = pack2<BF16>(q1 * c - q2 * sn, q2 * c + q1 * sn);
-            const uint32_t kp2 = pack2<BF16>(k1 * c - k2 * sn, k2 * c + k1 * sn);
+            // HF apply_rotary_pos_emb on 16-bit tensors: every product is stored before the sum (same as k_rope)
+            auto r = [](float f) { return cvt16<BF16>((uint16_t)pack2<BF16>(f, 0.f)); };
+            const uint32_t qp = pack2<BF16>(r(q1 * c) - r(q2 * sn), r(q2 * c) + r(q1 * sn));
+            const uint32_t kp2 = pack2<BF16>(r(k1 * c) - r(k2 * sn), r(k2 * c) + r(k1 * sn));
             q1 = cvt16<BF16>((uint16_t)qp);
             q2 = cvt16<BF16>((uint16_t)(qp >> 16));
             kr1 = (uint16_t)kp2;

@@ -100,7 +100,10 @@ k_norm(const uint16_t* __restrict__ x, const float* __restrict__ w, const float*
             }
             uint16_t o[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = st16<BF16>((v[c][j] - mean) * rstd * ww[j] + bb[j]);
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (RMS) o[j] = st16<BF16>(ld16<BF16>(st16<BF16>(v[c][j] * rstd)) * ww[j]);      // HF Phi3RMSNorm: weight * x_hat.to(dtype)
+                else o[j] = st16<BF16>((v[c][j] - mean) * rstd * ww[j] + bb[j]);
+            }
             *reinterpret_cast<uint4*>(yr + off) = *reinterpret_cast<const uint4*>(o);
         }
     }
@@ -130,8 +133,9 @@ __global__ void k_rope(uint16_t* __restrict__ qkv, const float* __restrict__ cos
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float x1 = ld16<BF16>(ah[j]), x2 = ld16<BF16>(bh[j]);
-        o1[j] = st16<BF16>(x1 * cc[j] - x2 * ss[j]);
-        o2[j] = st16<BF16>(x2 * cc[j] + x1 * ss[j]);
+        // HF apply_rotary_pos_emb on 16-bit tensors: (x * cos) + (rotate_half(x) * sin), every product and the sum stored 16-bit
+        o1[j] = st16<BF16>(ld16<BF16>(st16<BF16>(x1 * cc[j])) - ld16<BF16>(st16<BF16>(x2 * ss[j])));
+        o2[j] = st16<BF16>(ld16<BF16>(st16<BF16>(x2 * cc[j])) + ld16<BF16>(st16<BF16>(x1 * ss[j])));
     }
     *reinterpret_cast<uint4*>(base) = *reinterpret_cast<const uint4*>(o1);
     *reinterpret_cast<uint4*>(base + half) = *reinterpret_cast<const uint4*>(o2);
@@ -205,7 +209,7 @@ __global__ void k_swiglu(const uint16_t* __restrict__ gu, uint16_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float gv = ld16<BF16>(gh[j]);
-        o[j] = st16<BF16>(ld16<BF16>(uh[j]) * (gv / (1.0f + __expf(-gv))));
+        o[j] = st16<BF16>(ld16<BF16>(uh[j]) * ld16<BF16>(st16<BF16>(gv / (1.0f + __expf(-gv)))));      // silu's result is a 16-bit tensor (HF Phi3MLP)
     }
     *reinterpret_cast<uint4*>(out + i) = *reinterpret_cast<const uint4*>(o);
 }

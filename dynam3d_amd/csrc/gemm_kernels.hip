@@ -130,19 +130,40 @@ __device__ __forceinline__ void stage_tile_dma(const TileLanes<WAVES>& tl, const
         : "memory");
 }
 
+// One 1 KiB piece (8 rows x 128 B) of an operand tile; `dst` = wave-uniform LDS byte address of the piece.
+__device__ __forceinline__ void stage_piece_dma(uint32_t voff, const uint16_t* __restrict__ base, uint32_t dst) {
+    const uint32_t d = __builtin_amdgcn_readfirstlane(dst);
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(d), "s"(base)
+        : "memory");
+}
+
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
 
 // Epilogue for one 16-column MFMA tile of one output row: this lane owns columns n16 + fg*4 .. +3.
 // SWIGLU: `a` is the gate tile, `b` the matching up tile (weights interleaved per 16 rows); output column n16/2.
+// Rounding points = the reference's module boundaries (include/dynam3d_hip.h "ROUNDING POINTS"): r16() is a store-and-reload
+// in the 16-bit dtype on the fp32 register.
+template <bool BF16>
+__device__ __forceinline__ float r16(float f) { return to_f32<BF16>(from_f32<BF16>(f)); }
+
 template <bool BF16, int EPI>
 __device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
                                        const uint16_t* __restrict__ residual, int m, int n16, int fg, int64_t ldc) {
     uint16_t o[4];
     if constexpr (EPI == EPI_SWIGLU) {
+        // HF Phi3MLP: gate_up = linear(x) [16-bit]; up * silu(gate) with silu's result and the product stored 16-bit
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = from_f32<BF16>(b[r] * act_silu(a[r]));
+        for (int r = 0; r < 4; ++r) o[r] = from_f32<BF16>(r16<BF16>(b[r]) * r16<BF16>(act_silu(r16<BF16>(a[r]))));
         *reinterpret_cast<uint2*>(C + (int64_t)m * ldc + n16 / 2 + fg * 4) = *reinterpret_cast<const uint2*>(o);
     } else {
         const int n = n16 + fg * 4;
@@ -153,13 +174,17 @@ __device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint1
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += to_f32<BF16>(bp[r]);
         }
-        if constexpr (EPI == EPI_BIAS_QGELU) {
+        if constexpr (EPI == EPI_BIAS_QGELU) {          // x * sigmoid(1.702 * x) on 16-bit tensors (clip/model.py:162-164)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_qgelu(v[r]);
+            for (int r = 0; r < 4; ++r) {
+                const float x = r16<BF16>(v[r]);
+                const float t = r16<BF16>(1.702f * x);
+                v[r] = x * r16<BF16>(1.0f / (1.0f + __expf(-t)));
+            }
         }
         if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_gelu(v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = act_gelu(r16<BF16>(v[r]));
         }
         if constexpr (EPI == EPI_LRELU) {          // tcnn CutlassMLP hidden activation (slope 0.01), PRE-FF:221-243
 #pragma unroll
@@ -169,7 +194,7 @@ __device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint1
             const uint2 rr = *reinterpret_cast<const uint2*>(residual + (int64_t)m * ldc + n);
             const uint16_t* rp = reinterpret_cast<const uint16_t*>(&rr);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += to_f32<BF16>(rp[r]);
+            for (int r = 0; r < 4; ++r) v[r] = r16<BF16>(v[r]) + to_f32<BF16>(rp[r]);      // x + linear(...): the linear's output is a 16-bit tensor
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = from_f32<BF16>(v[r]);
@@ -296,7 +321,7 @@ constexpr int TM = 256, TN = 256, T_THREADS = 512;
 // that would not fill a round, each cut into `splits` K-slices so that the partial last round lasts 1/splits of a tile
 // instead of a whole one.  Every slice writes its fp32 accumulators to the workspace, waits for its siblings (one counter per
 // tile) and then reduces + finishes ITS share of the tile, summing in slice order -- deterministic.
-template <bool BF16, int EPI, bool KFULL, bool SPLIT>
+template <bool BF16, int EPI, bool KFULL, bool SPLIT, int DMAV = 0>
 __global__ void __launch_bounds__(T_THREADS, 2)
 k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* __restrict__ C,
               const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, int M, int N, int K, int64_t lda,
@@ -378,6 +403,39 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     // barrier up front, so it always runs exactly one step behind group 0 (and group 0 one extra at the end).
     // Tile t+1 goes in flight at the start of tile t and must have landed one step before group 0 reads it:
     // group 0 drains its share at the end of its last step of the tile, group 1 (a step late) one step earlier.
+    if constexpr (DMAV == 1) {
+        // DMAV 1: the A pieces of tile t+1 are issued in the LOAD phase, the W pieces between the MFMAs of the COMPUTE phase
+        // (tile t+1 for group 0, tile t+2 for group 1, whose COMPUTE(t) runs beside group 0's LOAD(t+1)): the LOAD phase --
+        // 8 LDS-DMA issues + 24 ds_read_b128 -- was longer than the partner's 64 MFMAs.
+        static_assert(KFULL && !SPLIT, "DMAV 1 is built on the whole-K-tile, unsplit loop");
+        if (grp == 1) {
+            if (kb + 1 < ke) stage_tile_dma<8>(tw, wbase + (kb + 1) * BK, lds0 + (BUF * 2) + TM * BK * 2, wave);
+            __builtin_amdgcn_s_barrier();
+        }
+        for (int t = kb; t < ke; ++t) {
+            if (t + 1 < ke) stage_tile_dma<8>(ta, abase + (t + 1) * BK, lds0 + ((t + 1 - kb) & 1) * (BUF * 2), wave);
+            LOAD(t, 0, 0);
+            LOAD(t, 1, 1);
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            const int tw_t = t + 1 + grp;
+            const bool dma = tw_t < ke;
+            const uint16_t* wsrc = wbase + tw_t * BK;
+            const uint32_t wdst = lds0 + ((tw_t - kb) & 1) * (BUF * 2) + TM * BK * 2 + (uint32_t)wave * 1024u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<BF16>(bf[0][j], af[0][i], acc[i][j]);
+                if ((i & 1) == 0 && dma) stage_piece_dma(tw.off[i >> 1], wsrc, wdst + (uint32_t)(i >> 1) * 8192u);
+            }
+            COMPUTE(1);
+            __builtin_amdgcn_s_setprio(0);
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
     if (grp == 1) __builtin_amdgcn_s_barrier();
     for (int t = kb; t < ke; ++t) {
         if (t + 1 < ke) {
@@ -415,6 +473,7 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
             if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+    }
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
 
@@ -521,17 +580,18 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     }
 }
 
-template <bool BF16, int EPI, bool KFULL>
+template <bool BF16, int EPI, bool KFULL, int DMAV = 0>
 int32_t launch256(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
                   int64_t ldw, int64_t ldc, hipStream_t s) {
     const int tm = (M + TM - 1) / TM, tn = N / TN;
     const size_t sh = 2 * 2 * TM * BK * sizeof(uint16_t);   // 128 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, KFULL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL, false>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W,
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, KFULL, false, DMAV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    });
+    D3D_HIP(attr_err);
+    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL, false, DMAV>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W,
                        (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, 1, (float*)nullptr, (uint32_t*)nullptr);
     D3D_LAUNCH_CHECK();
 }
@@ -854,7 +914,7 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream) {
     if (M <= 0) return D3D_OK;
     if (tile == 16) return skinny_dispatch(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, dtype, epilogue, stream);
-    if (tile != 128 && tile != 130 && tile != 132 && tile != 256 && tile != 257 && tile != 258) {
+    if (tile != 128 && tile != 130 && tile != 132 && (tile < 256 || tile > 259)) {
         d3d_set_error_("d3d_gemm_nt_tile: tile must be 128 (130 / 132: 2 / 4 LDS stages forced), 256 (K-half steps), 257 (whole-K-tile steps) or 258 (257 + split-K tail)");
         return D3D_EINVAL;
     }
@@ -878,6 +938,9 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
         if (tile == 257)                                                                                              \
             return dtype == 0 ? launch256<true, E, true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)           \
                               : launch256<false, E, true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);         \
+        if (tile == 259)                                                                                              \
+            return dtype == 0 ? launch256<true, E, true, 1>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)        \
+                              : launch256<false, E, true, 1>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);      \
         return dtype == 0 ? launch<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s, tile == 128 ? 0 : tile - 128)  \
                           : launch<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s, tile == 128 ? 0 : tile - 128);
     switch (epilogue) {

@@ -14,9 +14,49 @@ import torch
 import torch.nn.functional as F
 
 BACKEND = {"linear": "torch/hipBLASLt", "attention": "torch/SDPA", "layer_norm": "torch", "rms_norm": "torch",
-           "rope": "torch", "swiglu": "torch", "resize_normalize": "torch"}
+           "rope": "torch", "swiglu": "torch", "resize_normalize": "torch", "vit_embed": "torch"}
 
 _hip = None  # set by enable_hip_kernels()
+
+# ---- strict mode + dispatch accounting ---------------------------------------------------------------------------
+# Every primitive below either launches a hand-written kernel ("hip") or -- when a shape / dtype predicate fails, or on
+# the CPU -- runs the PyTorch expression next to it.  On a GPU that second branch is a silent change of backend, so it is
+# counted per primitive, and under STRICT it raises instead: bench.py, smoke() and the GPU tower tests run strict, and the
+# benchmark line prints both tables (`fallbacks` must be empty).  CPU tensors are never counted: the CPU suite drives the
+# host logic through these expressions by design.
+STRICT = False
+COUNTS = {"hip": {}, "fallback": {}}
+
+
+class DenseFallbackError(RuntimeError):
+    pass
+
+
+def strict(on: bool = True):
+    """Raise `DenseFallbackError` whenever a CUDA tensor would take a PyTorch expression instead of a HIP kernel."""
+    global STRICT
+    STRICT = bool(on)
+
+
+def reset_counts():
+    COUNTS["hip"].clear()
+    COUNTS["fallback"].clear()
+
+
+def counts():
+    return {"hip": dict(COUNTS["hip"]), "fallback": dict(COUNTS["fallback"])}
+
+
+def _hit(prim: str):
+    COUNTS["hip"][prim] = COUNTS["hip"].get(prim, 0) + 1
+
+
+def _miss(prim: str, t: torch.Tensor, why: str):
+    if not t.is_cuda:
+        return
+    COUNTS["fallback"][prim] = COUNTS["fallback"].get(prim, 0) + 1
+    if STRICT:
+        raise DenseFallbackError(f"dense_ops.{prim}: no HIP kernel for this call ({why}); strict mode forbids the PyTorch expression")
 
 
 def enable_hip_kernels(which: Sequence[str] = ("all",)):
@@ -46,7 +86,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: Opt
     """y = act(x w^T + b) [+ residual].  x (M,K), w (N,K).  On the HIP backend bias / activation / residual are
     fused into the GEMM epilogue (csrc/gemm_kernels.hip)."""
     if BACKEND["linear"] == "hip" and x.is_cuda and _hip.gemm_ok(x, w):
+        _hit("linear")
         return _hip.linear(x, w, b, act, residual)
+    _miss("linear", x, f"backend {BACKEND['linear']}, x {tuple(x.shape)} {x.dtype}, w {tuple(w.shape)} {w.dtype}")
     y = _act(F.linear(x, w, b), act)
     return y if residual is None else y + residual.reshape(y.shape)
 
@@ -55,32 +97,66 @@ def linear_swiglu(x: torch.Tensor, w_gate_up: torch.Tensor, interleaved: bool) -
     """Phi-3 MLP front half: up * silu(gate) of x w^T.  `interleaved` says whether w's rows were re-laid-out by
     hip_dense.interleave_gate_up (per-16 gate/up blocks) for the fused-epilogue kernel."""
     if interleaved and BACKEND["linear"] == "hip" and x.is_cuda and _hip.gemm_ok(x, w_gate_up):
+        _hit("linear_swiglu")
         return _hip.linear_swiglu(x, w_gate_up)
+    _miss("linear_swiglu", x, f"interleaved {interleaved}, x {tuple(x.shape)} {x.dtype}, w {tuple(w_gate_up.shape)}")
     gu = F.linear(x, w_gate_up)
     if interleaved:
         I = gu.shape[-1] // 2
         gu = gu.view(-1, I // 16, 2, 16)
         g, u = gu[:, :, 0].reshape(-1, I), gu[:, :, 1].reshape(-1, I)
-        return (u.float() * F.silu(g.float())).to(x.dtype)
+        return u * F.silu(g)                                  # HF Phi3MLP on the activations' dtype: silu and the product are stored
     return swiglu(gu)
+
+
+def r16(x: torch.Tensor, dtype) -> torch.Tensor:
+    """A 16-bit store-and-reload at one of the reference's module boundaries (no-op for float32 towers)."""
+    return x if dtype == torch.float32 else x.to(dtype).to(x.dtype)
+
+
+def vit_embed(pixels: torch.Tensor, patch_w: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
+              patch: int, eps: float = 1e-5) -> torch.Tensor:
+    """ViT embeddings + ln_pre (clip/model.py:222-228): conv(patch, stride patch, no bias) as a GEMM over unfolded patches,
+    [cls; patches] + positional embedding, LayerNorm.  pixels (B,3,S,S) f32; patch_w (W, Kp) with Kp = 3*patch^2 rounded up to
+    a multiple of 64 (zero columns); cls (W), pos (L, W) in the tower's dtype.  -> (B, L, W)."""
+    B, _, S, _ = pixels.shape
+    G = S // patch
+    dt = patch_w.dtype
+    K = 3 * patch * patch
+    if BACKEND["vit_embed"] == "hip" and pixels.is_cuda and dt in (torch.bfloat16, torch.float16) and _hip.gemm_ok(patch_w[:1], patch_w):
+        _hit("vit_embed")
+        rows = _hip.patchify(pixels, patch, patch_w.shape[1], dt)
+        x = linear(rows, patch_w, None)
+        return _hip.vit_embed_ln(x, cls, pos, ln_w, ln_b, B, eps)
+    _miss("vit_embed", pixels, f"dtype {dt}, patch_w {tuple(patch_w.shape)}")
+    pt = pixels.to(dt).view(B, 3, G, patch, G, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * G * G, K)
+    x = F.linear(pt, patch_w[:, :K]).view(B, G * G, -1)
+    x = torch.cat([cls.expand(B, 1, -1).to(x.dtype), x], dim=1) + pos.to(x.dtype)          # a 16-bit add in the 16-bit towers
+    return layer_norm(x, ln_w, ln_b, eps)
 
 
 def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
     """float32 statistics and affine, result in x.dtype (clip/model.py:153-159)."""
     if BACKEND["layer_norm"] == "hip" and x.is_cuda and _hip.norm_ok(x):
+        _hit("layer_norm")
         return _hip.layer_norm(x, w, b, eps)
+    _miss("layer_norm", x, f"x {tuple(x.shape)} {x.dtype}")
     return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps).to(x.dtype)
 
 
 def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     if BACKEND["rms_norm"] == "hip" and x.is_cuda and _hip.norm_ok(x):
+        _hit("rms_norm")
         return _hip.rms_norm(x, w, eps)
+    _miss("rms_norm", x, f"x {tuple(x.shape)} {x.dtype}")
     xf = x.float()
-    return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * w).to(x.dtype)
+    xh = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype)          # HF Phi3RMSNorm: weight * x_hat.to(input_dtype)
+    return (xh.float() * w).to(x.dtype)
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool) -> torch.Tensor:
     """q,k,v (B,L,H,hd) (any strides) -> (B,L,H,hd) contiguous; softmax scale 1/sqrt(hd)."""
+    _miss("attention", q, f"SDPA on q {tuple(q.shape)} {q.dtype}")
     o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), is_causal=causal)
     return o.transpose(1, 2).contiguous()
 
@@ -90,6 +166,7 @@ def attention_qkv(qkv: torch.Tensor, n_heads: int, causal: bool) -> torch.Tensor
     HIP backend: flash kernel reading q/k/v in place (csrc/attn_kernels.hip); otherwise SDPA on strided views."""
     B, S, Ht, hd = qkv.shape
     if BACKEND["attention"] == "hip" and qkv.is_cuda and Ht == 3 * n_heads and _hip.attention_ok(qkv, hd):
+        _hit("attention")
         return _hip.attention_qkv(qkv, n_heads, causal)
     return attention(qkv[:, :, :n_heads], qkv[:, :, n_heads:2 * n_heads], qkv[:, :, 2 * n_heads:], causal)
 
@@ -101,11 +178,13 @@ def packed_ok(dtype, head_dim: int) -> bool:
 
 
 def rope_packed_(qkv2d: torch.Tensor, n_rot_heads: int, head_dim: int, cos, sin, pos: torch.Tensor):
+    _hit("rope")
     _hip.rope_inplace(qkv2d, cos, sin, 1, n_rot_heads, head_dim, pos)
     return qkv2d
 
 
 def attention_packed(qkv3: torch.Tensor, n_heads: int, causal: bool, cu_seqlens: torch.Tensor, n_seq: int, max_len: int, n_valid=None):
+    _hit("attention")
     return _hip.attention_packed(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid)
 
 
@@ -119,30 +198,36 @@ def rope_qk_(qkv: torch.Tensor, n_rot_heads: int, cos: torch.Tensor, sin: torch.
     B, S, Ht, hd = qkv.shape
     if (BACKEND["rope"] == "hip" and qkv.is_cuda and qkv.is_contiguous() and qkv.dtype in (torch.bfloat16, torch.float16)
             and (hd // 2) % 8 == 0):
+        _hit("rope")
         _hip.rope_inplace(qkv.view(B * S, Ht * hd), cos, sin, S, n_rot_heads, hd)
         return qkv
+    _miss("rope", qkv, f"qkv {tuple(qkv.shape)} {qkv.dtype}")
     return torch.cat([rope(qkv[:, :, :n_rot_heads], cos, sin), qkv[:, :, n_rot_heads:]], dim=2)
 
 
 def rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
     """Half-split rotary embedding (HF `rotate_half`): pairs (i, i+hd/2).  x (B,S,H,hd); cos/sin (S,hd/2) f32."""
     hd = x.shape[-1]
-    x1, x2 = x[..., : hd // 2].float(), x[..., hd // 2:].float()
-    c, s = cos[None, :, None, :], sin[None, :, None, :]
-    return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], dim=-1).to(x.dtype)
+    x1, x2 = x[..., : hd // 2], x[..., hd // 2:]
+    c, s = cos[None, :, None, :].to(x.dtype), sin[None, :, None, :].to(x.dtype)          # HF: cos/sin cast to the activations' dtype,
+    return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], dim=-1)                           # products and sums stored in it
 
 
 def swiglu(gu: torch.Tensor) -> torch.Tensor:
     """Phi-3 MLP: gate, up = chunk(gate_up, 2); up * silu(gate)."""
     if BACKEND["swiglu"] == "hip" and gu.is_cuda and gu.dtype in (torch.bfloat16, torch.float16) and gu.shape[-1] % 16 == 0:
+        _hit("swiglu")
         return _hip.swiglu(gu)
+    _miss("swiglu", gu, f"gu {tuple(gu.shape)} {gu.dtype}")
     g, u = gu.chunk(2, dim=-1)
-    return (u.float() * F.silu(g.float())).to(gu.dtype)
+    return u * F.silu(g)
 
 
 def resize_normalize(rgb_u8: torch.Tensor, size: int, mean, std) -> torch.Tensor:
     if BACKEND["resize_normalize"] == "hip" and rgb_u8.is_cuda:
+        _hit("resize_normalize")
         return _hip.resize_normalize(rgb_u8, size, mean, std)
+    _miss("resize_normalize", rgb_u8, "backend")
     x = rgb_u8.permute(0, 3, 1, 2).float()
     if x.shape[-1] != size or x.shape[-2] != size:
         x = F.interpolate(x, size=(size, size), mode="bicubic", align_corners=False)

@@ -21,6 +21,8 @@ _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
 _lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
 _lib.register("d3d_decode_attention", [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp])
 _lib.register("d3d_phi3_decode_token", [vp])
+_lib.register("d3d_patchify", [vp, vp, i32, i32, i32, i32, i32, vp])
+_lib.register("d3d_vit_embed_ln", [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp])
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -54,7 +56,7 @@ def ptr_array(tensors):
 
 
 class HipDense:
-    PRIMS = {"linear", "layer_norm", "rms_norm", "rope", "swiglu", "resize_normalize", "attention"}
+    PRIMS = {"linear", "layer_norm", "rms_norm", "rope", "swiglu", "resize_normalize", "attention", "vit_embed"}
 
     def __init__(self):
         self.lib = _lib.load()
@@ -152,6 +154,23 @@ class HipDense:
         """All launches of one KV-cache decode token, issued from C++ (d3d_phi3_decode_token)."""
         args.stream = self._stream()
         _lib.check(self.lib.d3d_phi3_decode_token(C.byref(args)))
+
+    def patchify(self, pixels, patch, Kp, dtype):
+        """pixels (B,3,S,S) f32 -> (B*(S/patch)^2, Kp) rows of unfolded patches in `dtype`, zero-padded columns (d3d_patchify)."""
+        px = pixels.contiguous()
+        B, _, S, _ = px.shape
+        G = S // patch
+        out = torch.empty((B * G * G, Kp), dtype=dtype, device=px.device)
+        _lib.check(self.lib.d3d_patchify(_p(px), _p(out), B, S, patch, Kp, 0 if dtype == torch.bfloat16 else 1, self._stream()))
+        return out
+
+    def vit_embed_ln(self, patch_rows, cls, pos, ln_w, ln_b, B, eps):
+        """[cls; patch rows] + pos (16-bit add) -> ln_pre -> (B, L, D)  (d3d_vit_embed_ln)."""
+        L, D = pos.shape
+        out = torch.empty((B, L, D), dtype=patch_rows.dtype, device=patch_rows.device)
+        _lib.check(self.lib.d3d_vit_embed_ln(_p(patch_rows), _p(cls), _p(pos), _p(ln_w), _p(ln_b), _p(out), B, L, D, eps,
+                                             0 if patch_rows.dtype == torch.bfloat16 else 1, self._stream()))
+        return out
 
     def resize_normalize(self, rgb_u8, size, mean, std):
         import numpy as np

@@ -126,18 +126,23 @@ class _VitTrunk:
     def _t(self, x):
         return x.detach().to(self.device, self.dtype).contiguous()
 
-    def _f(self, x):   # norm gains/biases and embeddings that are consumed in float32
+    def _f(self, x):   # norm gains/biases that are consumed in float32
         return x.detach().to(self.device, torch.float32).contiguous()
 
+    def _fq(self, x):  # float32 copies of parameters the REFERENCE holds in the tower's 16-bit dtype (HF `model.to(bfloat16)` casts the
+        return x.detach().to(self.device, self.dtype).to(torch.float32).contiguous()     # norm gains too): same values, fp32 container
+
+    def _patch_weight(self, w4):
+        """conv1.weight (W,3,P,P) -> (W, Kp): the GEMM's [out, in] operand, K zero-padded to a multiple of 64 (588 -> 640)."""
+        w = w4.reshape(w4.shape[0], -1)
+        Kp = (w.shape[1] + 63) // 64 * 64
+        out = torch.zeros((w.shape[0], Kp), dtype=self.dtype, device=self.device)
+        out[:, :w.shape[1]] = w.to(self.device, self.dtype)
+        return out
+
     def embed(self, pixels: torch.Tensor) -> torch.Tensor:
-        """pixels (B,3,336,336) normalised, tower dtype -> (B,577,width) after cls/pos/ln_pre."""
-        c = self.cfg
-        B = pixels.shape[0]
-        # conv14/stride14, no bias == GEMM over unfolded patches (B*576, 588) x (588, width)
-        pt = pixels.view(B, 3, c.grid, c.patch, c.grid, c.patch).permute(0, 2, 4, 1, 3, 5).reshape(B * c.grid * c.grid, 3 * c.patch * c.patch)
-        x = D.linear(pt, self.patch_w, None).view(B, c.grid * c.grid, c.width)
-        x = torch.cat([self.cls.expand(B, 1, c.width).to(x.dtype), x], dim=1) + self.pos.to(x.dtype)
-        return D.layer_norm(x, self.ln_pre[0], self.ln_pre[1], 1e-5)
+        """pixels (B,3,336,336) normalised float32 -> (B,577,width) after patch embedding, cls/pos and ln_pre (clip/model.py:222-228)."""
+        return D.vit_embed(pixels.float(), self.patch_w, self.cls, self.pos, self.ln_pre[0], self.ln_pre[1], self.cfg.patch, 1e-5)
 
     def run_blocks(self, x: torch.Tensor, n_layers: int) -> torch.Tensor:
         c = self.cfg
@@ -157,7 +162,7 @@ class ClipVisionTower(_VitTrunk):
     def __init__(self, sd: Dict[str, torch.Tensor], cfg: VitConfig = VitConfig(), dtype=torch.float16, device="cuda"):
         super().__init__(cfg, dtype, device)
         t, f = self._t, self._f
-        self.patch_w = t(sd["visual.conv1.weight"].reshape(cfg.width, -1))
+        self.patch_w = self._patch_weight(sd["visual.conv1.weight"])
         self.cls, self.pos = t(sd["visual.class_embedding"]), t(sd["visual.positional_embedding"])
         self.ln_pre = (f(sd["visual.ln_pre.weight"]), f(sd["visual.ln_pre.bias"]))
         self.ln_post = (f(sd["visual.ln_post.weight"]), f(sd["visual.ln_post.bias"]))
@@ -175,7 +180,7 @@ class ClipVisionTower(_VitTrunk):
     def forward(self, pixels: torch.Tensor):
         """-> (cls (B,768), patches (B,576,768)) in tower dtype (clip/model.py:219-238)."""
         c = self.cfg
-        x = self.run_blocks(self.embed(pixels.to(self.dtype)), c.layers)
+        x = self.run_blocks(self.embed(pixels), c.layers)
         x = D.layer_norm(x, self.ln_post[0], self.ln_post[1], 1e-5)          # ln_post on ALL tokens
         B, L, W = x.shape
         y = D.linear(x.view(B * L, W), self.proj_w, None).view(B, L, c.out_dim)
@@ -186,9 +191,9 @@ class LlavaVisionTower(_VitTrunk):
     def __init__(self, sd: Dict[str, torch.Tensor], cfg: VitConfig = VitConfig(), dtype=torch.bfloat16, device="cuda",
                  feature_layer: int = -2):
         super().__init__(cfg, dtype, device)
-        t, f = self._t, self._f
+        t, f = self._t, self._fq                         # HF `torch_dtype=bfloat16` casts the LayerNorm parameters as well
         v = "vision_tower.vision_model"
-        self.patch_w = t(sd[v + ".embeddings.patch_embedding.weight"].reshape(cfg.width, -1))
+        self.patch_w = self._patch_weight(sd[v + ".embeddings.patch_embedding.weight"])
         self.cls, self.pos = t(sd[v + ".embeddings.class_embedding"]), t(sd[v + ".embeddings.position_embedding.weight"])
         self.ln_pre = (f(sd[v + ".pre_layrnorm.weight"]), f(sd[v + ".pre_layrnorm.bias"]))
         self.n_run = cfg.layers + 1 + feature_layer          # hidden_states[-2] == output of layer (L-1)
@@ -210,7 +215,7 @@ class LlavaVisionTower(_VitTrunk):
     def forward(self, pixels: torch.Tensor) -> torch.Tensor:
         """-> (B,576,3072): llava.get_image_features(layer -2, 'default') (VLN-POL:448-452)."""
         c = self.cfg
-        x = self.run_blocks(self.embed(pixels.to(self.dtype)), self.n_run)[:, 1:]
+        x = self.run_blocks(self.embed(pixels), self.n_run)[:, 1:]
         B, L, W = x.shape
         h = D.linear(x.reshape(B * L, W), self.p1[0], self.p1[1], act="gelu")
         return D.linear(h, self.p2[0], self.p2[1]).view(B, L, c.proj_dim)
@@ -223,7 +228,7 @@ class Phi3Decoder:
     def __init__(self, sd: Dict[str, torch.Tensor], cfg: Phi3Config = Phi3Config(), dtype=torch.bfloat16, device="cuda"):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         t = lambda x: x.detach().to(self.device, dtype).contiguous()
-        f = lambda x: x.detach().to(self.device, torch.float32).contiguous()
+        f = lambda x: x.detach().to(self.device, dtype).to(torch.float32).contiguous()   # RMSNorm gains: values of the LM's dtype (HF casts them)
         m = "language_model.model"
         self.embed_w = t(sd[m + ".embed_tokens.weight"])
         # gate/up rows interleaved per 16 for the fused SwiGLU GEMM epilogue (only when the HIP GEMM is active)
@@ -250,7 +255,8 @@ class Phi3Decoder:
             c = self.cfg
             inv = 1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.float32, device=self.device) / c.head_dim))
             ang = torch.arange(S, dtype=torch.float32, device=self.device)[:, None] * inv[None]
-            self._rope_cache[S] = (ang.cos().contiguous(), ang.sin().contiguous())       # (S, hd/2) float32
+            # HF Phi3RotaryEmbedding returns cos / sin cast to the activations' dtype: float32 containers of those values
+            self._rope_cache[S] = (ang.cos().to(self.dtype).float().contiguous(), ang.sin().to(self.dtype).float().contiguous())   # (S, hd/2)
         return self._rope_cache[S]
 
     @torch.no_grad()

@@ -206,7 +206,13 @@ int32_t d3d_agent_frame_compact(const float* pool_pos_d, const float* pool_fts_d
  * Dense kernels for the ViT / Phi-3 towers (a3, a15, a17).  dtype: 0 = bf16, 1 = fp16 (16-bit storage,
  * fp32 accumulation / statistics).
  * ---------------------------------------------------------------------------------------------- */
-/* C = epilogue(A[M,K] W[N,K]^T): nn.Linear layout.  epilogue: 0 none, 1 +bias, 2 +bias QuickGELU (clip/model.py:162),
+/* ROUNDING POINTS.  The reference evaluates these towers module by module in fp16 (OpenAI CLIP after `convert_weights`,
+ * clip/model.py:373-395) / bf16 (llava, `torch_dtype=torch.bfloat16`, VLN-POL:125): every nn.Linear, activation, residual add, norm
+ * and rotary product STORES a 16-bit tensor.  The fused kernels below reproduce exactly those stores on their fp32 registers
+ * (e.g. epilogue 5 = round16(round16(acc + bias) + residual), not round16(acc + bias + residual)), so a fused launch returns what
+ * the module sequence returns; inside a GEMM / attention the accumulation is float32 like the reference's library kernels.
+ *
+ * C = epilogue(A[M,K] W[N,K]^T): nn.Linear layout.  epilogue: 0 none, 1 +bias, 2 +bias QuickGELU (clip/model.py:162),
  * 3 +bias GELU, 4 +residual, 5 +bias +residual, 6 SwiGLU over per-16 interleaved gate/up rows of W (writes N/2 cols).
  * Needs N % 128 == 0, K % 64 == 0, lda/ldw % 8 == 0.  M <= 16 (KV-cache decode rows) with epilogue 0/1/4/6 streams the weights
  * once through a no-LDS kernel (N % 32 == 0, K % 32 == 0 suffice there). */
@@ -266,10 +272,13 @@ int32_t d3d_decode_attention(const void* qkv_new_d, const void* prompt_qkv_d, co
                              void* out_d, int32_t B, int32_t H, int32_t head_dim, int32_t t_new, int32_t Tmax, int32_t max_prompt_len,
                              const float* cos_d, const float* sin_d, const int32_t* pos_d /* all three or none: fused RoPE of q, k */,
                              int32_t dtype, void* stream);
-/* LayerNorm (rms = 0; clip/model.py:153-159: float32 statistics) or RMSNorm (rms = 1; Phi-3) over rows of D <= 4096 */
+/* LayerNorm (rms = 0; clip/model.py:153-159: float32 statistics, one 16-bit store) or RMSNorm (rms = 1; HF Phi3RMSNorm:
+ * `weight * x_normalised.to(input_dtype)` -- the normalised row is stored 16-bit BEFORE the gain is applied) over rows of D <= 4096 */
 int32_t d3d_norm(const void* x_d, const float* w_d, const float* b_d, void* y_d, int32_t rows, int32_t D, int64_t ldx,
                  int64_t ldy, float eps, int32_t rms, int32_t dtype, void* stream);
-/* in-place half-split rotary embedding on the first n_rot_heads heads of each fused-QKV row; position = row % S */
+/* in-place half-split rotary embedding on the first n_rot_heads heads of each fused-QKV row; position = row % S.  HF
+ * `apply_rotary_pos_emb` on 16-bit tensors: round16(round16(x*cos) + round16(rotate_half(x)*sin)), cos/sin tables holding
+ * 16-bit-representable values (the caller rounds them: HF casts cos/sin to the activations' dtype) */
 int32_t d3d_rope_inplace(void* qkv_d, const float* cos_d, const float* sin_d, int32_t rows, int32_t S, int32_t n_rot_heads,
                          int32_t head_dim, int64_t ld, const int32_t* pos_of_row_d /* optional: explicit position per row */,
                          int32_t dtype, void* stream);
@@ -291,6 +300,15 @@ int32_t d3d_set_attention(const float* qkv_d, const int32_t* set_off_d, int32_t 
 /* a3 front-end (resnet_encoders.py:267-271): uint8 HWC -> bicubic SxS (rounded back to uint8) -> /255 -> normalise, f32 CHW */
 int32_t d3d_resize_normalize(const uint8_t* rgb_d, float* out_d, int32_t B, int32_t H, int32_t W, int32_t S,
                              const float* mean3_h, const float* std3_h, void* stream);
+
+/* a3 / a15 patch embedding, A operand (clip/model.py:206, 222 `conv1`, stride = kernel = patch, no bias == a GEMM over unfolded
+ * patches): normalised float32 CHW pixels (B,3,S,S) -> (B*(S/patch)^2, Kp) rows in the tower's dtype, k = c*patch^2 + i*patch + j,
+ * columns [3*patch^2, Kp) zero (Kp % 64 == 0 for d3d_gemm_nt: 588 -> 640). */
+int32_t d3d_patchify(const float* pixels_d, void* out_d, int32_t B, int32_t S, int32_t patch, int32_t Kp, int32_t dtype, void* stream);
+/* a3 / a15 embeddings (clip/model.py:224-228): y[b,0] = LN(cls + pos[0]), y[b,1+p] = LN(patch_rows[b*(L-1)+p] + pos[1+p]); the sum is
+ * rounded to the 16-bit dtype before ln_pre, as the reference's 16-bit add is.  cls (D), pos (L,D), patch_rows (B*(L-1),D), y (B*L,D). */
+int32_t d3d_vit_embed_ln(const void* patch_rows_d, const void* cls_d, const void* pos_d, const float* ln_w_d, const float* ln_b_d, void* y_d,
+                         int32_t B, int32_t L, int32_t D, float eps, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pretrain novel-view renderer.  The 768-wide tcnn MLPs (PRE-FF:221-243, 484, 488) are
