@@ -319,14 +319,13 @@ constexpr int TM = 256, TN = 256, T_THREADS = 512;
 
 // SPLIT: the grid is `dp_tiles` whole tiles (a multiple of the CU count: full rounds, data parallel) followed by the TAIL tiles
 // that would not fill a round, each cut into `splits` K-slices so that the partial last round lasts 1/splits of a tile
-// instead of a whole one.  Every slice writes its fp32 accumulators to the workspace, waits for its siblings (one counter per
-// tile) and then reduces + finishes ITS share of the tile, summing in slice order -- deterministic.
+// instead of a whole one.  Every slice writes its fp32 accumulators to the workspace and leaves; k_splitk_fixup (the next launch)
+// sums the slices in slice order -- deterministic -- and runs the fused epilogue.
 template <bool BF16, int EPI, bool KFULL, bool SPLIT, int DMAV = 0>
 __global__ void __launch_bounds__(T_THREADS, 2)
 k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* __restrict__ C,
               const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, int M, int N, int K, int64_t lda,
-              int64_t ldw, int64_t ldc, int tiles_m, int tiles_n, int dp_tiles, int splits, float* __restrict__ ws,
-              uint32_t* __restrict__ counters) {
+              int64_t ldw, int64_t ldc, int tiles_m, int tiles_n, int dp_tiles, int splits, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2][A 256x64 | B 256x64]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = K / BK;
@@ -479,89 +478,15 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
 
     if constexpr (SPLIT) {
         if (tail_idx >= 0) {
-            // Partials travel with system-scope stores/loads (sc0 sc1), not agent-scope fences: a fence writes back / invalidates
-            // the XCD's whole L2 under every other workgroup's operand stream.  SGPR base + one VGPR offset per access.
-            constexpr uint32_t ROW = T_THREADS * 16u;                              // one float4 per thread
-            constexpr uint32_t SLOT = 32u * ROW;                                   // 256 KiB of fp32 per (tile, slice)
-            const char* tile_ws = reinterpret_cast<const char*>(ws) + (int64_t)tail_idx * splits * SLOT;
-            {
-                const char* slot = tile_ws + (int64_t)slice * SLOT;
-                uint32_t vo = (uint32_t)tid * 16u;
+            // A K-slice of a tail tile: its fp32 accumulators go to the workspace slot (tile, slice) -- entry e = i*4 + j holds
+            // acc[i][j] of all 512 threads, 16 bytes each -- and the workgroup LEAVES.  k_splitk_fixup, the next launch on the
+            // stream, sums the slices in slice order and runs the epilogue: no workgroup ever waits for another one, so the
+            // scheme needs no co-residency and cannot deadlock however the chip is shared (other streams, processes, CU masks).
+            float4v* slot = reinterpret_cast<float4v*>(ws) + ((int64_t)tail_idx * splits + slice) * (32 * T_THREADS) + tid;
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\tv_add_u32 %0, 0x2000, %0" : "+v"(vo) : "v"(acc[i][j]), "s"(slot) : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            // arrive, then wait for the other slices of this tile.  All slices of all tail tiles fit one round (tail * splits <=
-            // CUs), so they are resident together and the wait cannot deadlock.
-            if (tid == 0) {
-                __hip_atomic_fetch_add(counters + tail_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                while (__hip_atomic_load(counters + tail_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (uint32_t)splits) __builtin_amdgcn_s_sleep(2);
-            }
-            __syncthreads();
-            // reduce-scatter: the tile's 16 (row group, column pair) units are dealt out to the slices; each slice sums ITS units
-            // over all slices in slice order (deterministic) and runs the fused epilogue on them -- the fix-up is parallel
-            // over the slices instead of one workgroup reading splits x 256 KiB.
-            const int u0 = slice * 16 / splits, u1 = (slice + 1) * 16 / splits;
-            for (int u = u0; u < u1; u += 2) {
-                float4v part[2][8][2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int uu = (u + h < u1) ? u + h : u;                    // (odd count: the second half repeats the first, unused)
-                    const char* unit = tile_ws + (uint32_t)(uu * 2) * ROW;      // slot e = i*4 + j with i = uu/2, j = (uu&1)*2 -> e = uu*2
-#pragma unroll
-                    for (int sl = 0; sl < 8; ++sl) {
-                        part[h][sl][0] = float4v{0.f, 0.f, 0.f, 0.f};
-                        part[h][sl][1] = float4v{0.f, 0.f, 0.f, 0.f};
-                        if (sl < splits) {
-                            const char* src = unit + (int64_t)sl * SLOT;
-                            const uint32_t vo = (uint32_t)tid * 16u;
-                            asm volatile("global_load_dwordx4 %0, %2, %3 sc0 sc1\n\tglobal_load_dwordx4 %1, %2, %4 sc0 sc1"
-                                         : "=&v"(part[h][sl][0]), "=&v"(part[h][sl][1])
-                                         : "v"(vo), "s"(src), "s"(src + ROW)
-                                         : "memory");
-                        }
-                    }
-                }
-                // these loads are invisible to hipcc's waitcnt bookkeeping: tie every result to the wait
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    asm volatile("s_waitcnt vmcnt(0)"
-                                 : "+v"(part[h][0][0]), "+v"(part[h][0][1]), "+v"(part[h][1][0]), "+v"(part[h][1][1]), "+v"(part[h][2][0]), "+v"(part[h][2][1]),
-                                   "+v"(part[h][3][0]), "+v"(part[h][3][1]), "+v"(part[h][4][0]), "+v"(part[h][4][1]), "+v"(part[h][5][0]), "+v"(part[h][5][1]),
-                                   "+v"(part[h][6][0]), "+v"(part[h][6][1]), "+v"(part[h][7][0]), "+v"(part[h][7][1])
-                                 :
-                                 : "memory");
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (u + h >= u1) break;
-                    float4v s0 = part[h][0][0], s1 = part[h][0][1];
-#pragma unroll
-                    for (int sl = 1; sl < 8; ++sl) {                            // (slices >= splits hold zeros)
-                        s0 += part[h][sl][0];
-                        s1 += part[h][sl][1];
-                    }
-                    const int uu = u + h;
-                    const int m = row0 + grp * 128 + (uu >> 1) * 16 + fi;
-                    const int n16 = col0 + wn * 64 + (uu & 1) * 32;
-                    if (m < M) {
-                        if constexpr (EPI == EPI_SWIGLU) {
-                            store4<BF16, EPI>(s0, s1, C, bias, residual, m, n16, fg, ldc);
-                        } else {
-                            store4<BF16, EPI>(s0, s0, C, bias, residual, m, n16, fg, ldc);
-                            store4<BF16, EPI>(s1, s1, C, bias, residual, m, n16 + 16, fg, ldc);
-                        }
-                    }
-                }
-            }
-            // leave; the last slice to leave re-arms the counter for the next launch on this stream
-            if (tid == 0) {
-                if (__hip_atomic_fetch_add(counters + tail_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == (uint32_t)(2 * splits - 1))
-                    __hip_atomic_store(counters + tail_idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+                for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[i][j], slot + (i * 4 + j) * T_THREADS);
             return;
         }
     }
@@ -592,15 +517,56 @@ int32_t launch256(const void* A, const void* W, void* C, const void* bias, const
     });
     D3D_HIP(attr_err);
     hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL, false, DMAV>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W,
-                       (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, 1, (float*)nullptr, (uint32_t*)nullptr);
+                       (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, 1, (float*)nullptr);
     D3D_LAUNCH_CHECK();
 }
 
-// Per-stream workspace of the split-K tail: 256 KiB of fp32 per (tail tile, slice) -- at most one round of them -- and one
-// arrival counter per tail tile (the last slice to arrive resets it).  Streams never share a workspace.
+// Fix-up of the split-K tail: workgroup (tile, i) sums entries e = i*4 .. i*4+3 of the tile's `splits` slots in slice order and
+// runs the GEMM's own epilogue on them (same thread -> element mapping as k_gemm_nt_256: thread tid of the GEMM held these values).
+template <bool BF16, int EPI>
+__global__ void __launch_bounds__(T_THREADS)
+k_splitk_fixup(const float* __restrict__ ws, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual,
+               int M, int64_t ldc, int tiles_m, int tiles_n, int dp_tiles, int splits) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tail_idx = blockIdx.x >> 3, i = blockIdx.x & 7;
+    const int wg = dp_tiles + tail_idx;
+    constexpr int GM = 4;                                       // the tile order of k_gemm_nt_256
+    const int group = wg / (GM * tiles_n);
+    const int gm0 = group * GM;
+    const int gsz = min(GM, tiles_m - gm0);
+    const int tm = gm0 + (wg % (GM * tiles_n)) % gsz;
+    const int tn = (wg % (GM * tiles_n)) / gsz;
+    const int row0 = tm * TM, col0 = tn * TN;
+    const int grp = wave >> 2, wn = wave & 3, fi = lane & 15, fg = lane >> 4;
+    const float4v* base = reinterpret_cast<const float4v*>(ws) + (int64_t)tail_idx * splits * (32 * T_THREADS) + (i * 4) * T_THREADS + tid;
+    float4v sum[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum[j] = __builtin_nontemporal_load(base + j * T_THREADS);
+    for (int sl = 1; sl < splits; ++sl) {
+        const float4v* p = base + (int64_t)sl * (32 * T_THREADS);
+        float4v v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_nontemporal_load(p + j * T_THREADS);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum[j] += v[j];
+    }
+    const int m = row0 + grp * 128 + i * 16 + fi;
+    if (m >= M) return;
+    if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) store4<BF16, EPI>(sum[j], sum[j + 1], C, bias, residual, m, col0 + wn * 64 + j * 16, fg, ldc);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) store4<BF16, EPI>(sum[j], sum[j], C, bias, residual, m, col0 + wn * 64 + j * 16, fg, ldc);
+    }
+}
+
+// Per-stream workspace of the split-K tail: 256 KiB of fp32 per (tail tile, slice), at most one round of them.  Streams never
+// share a workspace (a GEMM and its fix-up are ordered by the stream; two streams may run split GEMMs concurrently).  Allocated on
+// first use -- or ahead of time with d3d_gemm_reserve_workspace(stream), which is what a caller that captures the stream into a
+// hipGraph must do (no hipMalloc inside a capture).
 struct SplitWorkspace {
     float* ws = nullptr;
-    uint32_t* counters = nullptr;
     int slots = 0;
 };
 
@@ -611,13 +577,9 @@ int32_t split_workspace(hipStream_t s, int slots, SplitWorkspace** out) {
     SplitWorkspace& w = table[s];
     if (w.slots < slots) {
         if (w.ws) (void)hipFree(w.ws);
-        if (w.counters) (void)hipFree(w.counters);
         w.ws = nullptr;
-        w.counters = nullptr;
         w.slots = 0;
         D3D_HIP(hipMalloc(&w.ws, (size_t)slots * 32 * T_THREADS * sizeof(float4v)));
-        D3D_HIP(hipMalloc(&w.counters, (size_t)slots * sizeof(uint32_t)));
-        D3D_HIP(hipMemset(w.counters, 0, (size_t)slots * sizeof(uint32_t)));
         w.slots = slots;
     }
     *out = &w;
@@ -625,11 +587,17 @@ int32_t split_workspace(hipStream_t s, int slots, SplitWorkspace** out) {
 }
 
 int cu_count() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
+    // per device: a process may drive several GPUs
+    static std::mutex mu;
+    static std::unordered_map<int, int> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = table.find(dev);
+    if (it != table.end()) return it->second;
+    int n = 0;
+    const int cus = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    table[dev] = cus;
     return cus;
 }
 
@@ -644,18 +612,6 @@ inline void split_plan(int tiles, int nk, int* dp_tiles, int* splits) {
     *splits = sp < 1 ? 1 : sp;
 }
 
-bool split_stream_ok(hipStream_t s) {
-    static std::mutex mu;
-    static bool owned = false;
-    static hipStream_t owner = nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!owned) {
-        owned = true;
-        owner = s;
-    }
-    return owner == s;
-}
-
 template <bool BF16, int EPI>
 int32_t launch256_split(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
                         int64_t ldw, int64_t ldc, hipStream_t s) {
@@ -663,23 +619,22 @@ int32_t launch256_split(const void* A, const void* W, void* C, const void* bias,
     int dp_tiles, splits;
     split_plan(tiles, K / BK, &dp_tiles, &splits);
     if (splits < 2) return launch256<BF16, EPI, true>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s);
-    // The sibling wait needs every slice of a launch's tail resident at once (tail * splits <= CUs, one workgroup per CU).  Two
-    // such launches running CONCURRENTLY on different streams could each hold half the chip while waiting for the other half,
-    // so only one stream per process -- the first that asks -- gets the split path; any other stream runs the unsplit kernel.
-    if (!split_stream_ok(s)) return launch256<BF16, EPI, true>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s);
     const int tail = tiles - dp_tiles;
     SplitWorkspace* w = nullptr;
     int32_t rc = split_workspace(s, cu_count(), &w);
     if (rc != D3D_OK) return rc;
     const size_t sh = 2 * 2 * TM * BK * sizeof(uint16_t);   // 128 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        attr_set = true;
-    }
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    });
+    D3D_HIP(attr_err);
     hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, true, true>), dim3(dp_tiles + tail * splits), dim3(T_THREADS), sh, s, (const uint16_t*)A,
                        (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, dp_tiles,
-                       splits, w->ws, w->counters);
+                       splits, w->ws);
+    hipLaunchKernelGGL((k_splitk_fixup<BF16, EPI>), dim3(tail * 8), dim3(T_THREADS), 0, s, (const float*)w->ws, (uint16_t*)C, (const uint16_t*)bias,
+                       (const uint16_t*)res, M, ldc, tm, tn, dp_tiles, splits);
     D3D_LAUNCH_CHECK();
 }
 
@@ -688,11 +643,12 @@ int32_t launch_stages(const void* A, const void* W, void* C, const void* bias, c
                       int64_t ldw, int64_t ldc, hipStream_t s) {
     const int tm = (M + BM - 1) / BM, tn = N / BN;
     const size_t sh = (size_t)NSTAGE * 2 * BM * BK * sizeof(uint16_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        D3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<BF16, EPI, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        attr_set = true;
-    }
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<BF16, EPI, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    });
+    D3D_HIP(attr_err);
     hipLaunchKernelGGL((k_gemm_nt<BF16, EPI, NSTAGE>), dim3(tm * tn), dim3(NTHREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
                        (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn);
     D3D_LAUNCH_CHECK();
@@ -855,6 +811,11 @@ extern "C" {
 // 16-byte aligned rows (lda, ldw multiples of 8).  M is arbitrary (edge tiles are masked).
 int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream);
+
+int32_t d3d_gemm_reserve_workspace(void* stream) {
+    SplitWorkspace* w = nullptr;
+    return split_workspace((hipStream_t)stream, cu_count(), &w);
+}
 
 int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
                     int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, void* stream) {

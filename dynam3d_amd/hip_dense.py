@@ -13,6 +13,7 @@ EPI = dict(none=0, bias=1, bias_quick_gelu=2, bias_gelu=3, res=4, bias_res=5, sw
 
 _lib.register("d3d_gemm_nt", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, vp])
 _lib.register("d3d_gemm_nt_tile", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32, vp])
+_lib.register("d3d_gemm_reserve_workspace", [vp])
 _lib.register("d3d_norm", [vp, vp, vp, vp, i32, i32, i64, i64, f32, i32, i32, vp])
 _lib.register("d3d_rope_inplace", [vp, vp, vp, i32, i32, i32, i32, i64, vp, i32, vp])
 _lib.register("d3d_set_attention", [vp, vp, i32, i32, i32, i32, vp, vp])

@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import dense_ops as D
+from .adapters import PromptTokenizer
 from .feature_fields import Feature_Fields
 from .profiling import TIMER
 from .towers import (ClipVisionTower, LlavaVisionTower, Phi3Config, Phi3Decoder, VitConfig, clip_param_spec,
@@ -51,19 +52,20 @@ def prefix_param_spec(width: int = 768, hidden: int = None):
     return s
 
 
-class SyntheticTokenizer:
+class SyntheticTokenizer(PromptTokenizer):
     """Deterministic stand-in for the llava-phi-3-mini tokenizer (its files are not available offline:
-    "parity unpinned" at this boundary).  Special tokens take the Phi-3 / llava ids; every other
-    whitespace-delimited piece is hashed into the ordinary vocabulary range."""
+    "parity unpinned" at this boundary; `adapters.HFTokenizerAdapter` wraps the real one).  Special tokens take the
+    Phi-3 / llava ids; every other whitespace-delimited piece is hashed into the ordinary vocabulary range.  Like
+    Phi-3's own tokenizer (`add_bos_token: true`) `encode` puts <s> in front of the text."""
     BOS, NEWLINE = 1, 13
     SPECIAL = {"<|user|>": 32010, "<|end|>": 32007, "<|assistant|>": 32001, "<image>": 32038, "<|endoftext|>": 32000}
 
-    def __init__(self, vocab: int = 32064):
-        self.vocab = vocab
+    def __init__(self, vocab: int = 32064, add_bos: bool = True):
+        self.vocab, self.add_bos = vocab, add_bos
         self._re = re.compile(r"(<\|[a-z]+\|>|<image>|\n|[^\s<]+|<)")
 
-    def encode(self, text: str, bos: bool = False) -> List[int]:
-        out = [self.BOS] if bos else []
+    def encode(self, text: str) -> List[int]:
+        out = [self.BOS] if self.add_bos else []
         hi = min(32000, self.vocab) - 100
         for piece in self._re.findall(text):
             if piece in self.SPECIAL:
@@ -242,32 +244,38 @@ class Dynam3D_VLN:
                 return self._assemble_packed(patch_feat, patch_pos, inst_tok, zone_tok, ni, nz, instructions, B, V)
             return self._assemble_rows(patch_feat, patch_pos, inst_tok, zone_tok, ni, nz, instructions, B, V, return_rows)
 
+    PROMPT_HEAD = "<|user|>\n"                                    # VLN-POL:436
+
     def _prompt_text(self, b, instructions):
         return ("\nInstruction:\n" + instructions[b] + "\nHistory actions:\n" + "".join(self.feature_fields.history_actions[b])
                 + "<|end|>\n<|assistant|>\nNext action:\n")
+
+    def _prompt_ids(self, b, instructions, n_visual):
+        """(ids in front of the visual prefix, ids behind it) = the reference's `inputs_embeds[:, :2]` / `[:, n_visual + 2:]` of the
+        prompt tokenised with one "<image>" per visual token (VLN-POL:436-438, 456): `PromptTokenizer.split_prompt`."""
+        return self.tokenizer.split_prompt(self.PROMPT_HEAD, n_visual, self._prompt_text(b, instructions))
 
     def _assemble_packed(self, patch_feat, patch_pos, inst_tok, zone_tok, ni, nz, instructions, B, V):
         """Same rows as `_assemble_rows`, written once, in the LM's dtype, back to back (no per-environment tensors, no
         padding): one id upload + one embedding gather for all prompts, one add for all patch tokens, one row gather into
         the packed buffer.  Returns (x (Tp, hidden) with Tp = sum(lengths) rounded up to 256 rows, lengths)."""
-        ff, tok, dt = self.feature_fields, self.tokenizer, self.cfg.llava_dtype
+        ff, dt = self.feature_fields, self.cfg.llava_dtype
         P = V * ff.P
-        head_ids = tok.encode("<|user|>", bos=True)
-        text_ids = [tok.encode(self._prompt_text(b, instructions)) for b in range(B)]
-        ids = torch.tensor(head_ids + [i for t in text_ids for i in t], device=self.device)
-        emb = self.llm.embed_tokens(ids).to(dt)                                                # rows [0, E)
+        parts = [self._prompt_ids(b, instructions, P + ni[b] + nz[b]) for b in range(B)]        # (head ids, tail ids) per prompt
+        ids = torch.tensor([i for h, t in parts for i in h + t], device=self.device)
+        emb = self.llm.embed_tokens(ids).to(dt)                                                # rows [0, E): head_0, tail_0, head_1, ...
         patch_tok = (patch_feat.reshape(B * P, -1).float() + patch_pos.reshape(B * P, -1).float()).to(dt)   # VLN-POL:448-453
         src = torch.cat([emb, patch_tok, inst_tok.to(dt), zone_tok.to(dt)], 0)
-        E, nh = emb.shape[0], len(head_ids)
+        E = emb.shape[0]
         o_patch, o_inst, o_zone = E, E + B * P, E + B * P + int(sum(ni))
         idx, lengths = [], []
-        t_off, i_off, z_off = nh, 0, 0
+        e_off, i_off, z_off = 0, 0, 0
         for b in range(B):                                                                     # VLN-POL:456 row order
-            n_t = len(text_ids[b])
-            idx.append(np.concatenate([np.arange(nh), o_patch + b * P + np.arange(P), o_inst + i_off + np.arange(ni[b]),
-                                       o_zone + z_off + np.arange(nz[b]), t_off + np.arange(n_t)]))
-            lengths.append(nh + P + ni[b] + nz[b] + n_t)
-            t_off, i_off, z_off = t_off + n_t, i_off + ni[b], z_off + nz[b]
+            n_h, n_t = len(parts[b][0]), len(parts[b][1])
+            idx.append(np.concatenate([e_off + np.arange(n_h), o_patch + b * P + np.arange(P), o_inst + i_off + np.arange(ni[b]),
+                                       o_zone + z_off + np.arange(nz[b]), e_off + n_h + np.arange(n_t)]))
+            lengths.append(n_h + P + ni[b] + nz[b] + n_t)
+            e_off, i_off, z_off = e_off + n_h + n_t, i_off + ni[b], z_off + nz[b]
         T = int(sum(lengths))
         Tp = (T + 255) // 256 * 256
         x = torch.zeros((Tp, src.shape[1]), dtype=dt, device=self.device)
@@ -281,13 +289,12 @@ class Dynam3D_VLN:
         patch_tok = patch_feat.float() + patch_pos                                             # VLN-POL:448-453
         patch_tok = patch_tok.view(B, V * ff.P, -1)
         # prompt (VLN-POL:436): ids 0..1 are kept in front of the visual prefix, the text follows it
-        tok = self.tokenizer
-        head = torch.tensor(tok.encode("<|user|>", bos=True), device=self.device)
-        head_e = self.llm.embed_tokens(head).float()
         rows, lengths = [], []
         io, zo = np.concatenate([[0], np.cumsum(ni)]), np.concatenate([[0], np.cumsum(nz)])
         for b in range(B):
-            te = self.llm.embed_tokens(torch.tensor(tok.encode(self._prompt_text(b, instructions)), device=self.device)).float()
+            h_ids, t_ids = self._prompt_ids(b, instructions, V * ff.P + ni[b] + nz[b])
+            head_e = self.llm.embed_tokens(torch.tensor(h_ids, device=self.device)).float()
+            te = self.llm.embed_tokens(torch.tensor(t_ids, device=self.device)).float()
             row = torch.cat([head_e, patch_tok[b], inst_tok[io[b]:io[b + 1]], zone_tok[zo[b]:zo[b + 1]], te], 0)   # VLN-POL:456
             rows.append(row)
             lengths.append(row.shape[0])

@@ -220,13 +220,17 @@ int32_t d3d_gemm_nt(const void* A_d, const void* W_d, void* C_d, const void* bia
                     int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
                     void* stream);
 /* same with an explicit tile: 128 = 128x128x64 (4 waves, 2 workgroups/CU), 256 / 257 = 256x256x64 staggered wave groups
- * stepping K-halves / whole K tiles, 258 = 257 with the partial last round of tiles split along K (fp32 partials in a
- * library-owned per-stream workspace, deterministic reduction; taken on ONE stream per process -- the first that asks --
- * because its slices wait for each other on the device); d3d_gemm_nt picks one (and splits the M remainder) itself.
- * epilogue 7 = LeakyReLU(0.01) for the tcnn CutlassMLP replacement. */
+ * stepping K-halves / whole K tiles, 258 = 257 with the partial last round of tiles split along K: the K-slices write fp32
+ * partials to a library-owned per-stream workspace and a second launch on the same stream sums them in slice order
+ * (deterministic) and runs the epilogue -- no workgroup waits for another one, any number of streams / processes may share
+ * the GPU.  259 = experiment (LDS-DMA of W issued between the MFMAs).  d3d_gemm_nt picks a tile (and splits the M remainder)
+ * itself.  epilogue 7 = LeakyReLU(0.01) for the tcnn CutlassMLP replacement. */
 int32_t d3d_gemm_nt_tile(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
                          int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
                          int32_t tile, void* stream);
+/* Allocates the split-K workspace of `stream` (64 MiB) now instead of inside the first d3d_gemm_nt that needs it: required before
+ * the stream is captured into a hipGraph (no allocation may happen during capture). */
+int32_t d3d_gemm_reserve_workspace(void* stream);
 /* tinycudann `Network(otype="CutlassMLP")` forward in one call (PRE-FF:221-243, 484, 488): n_hidden + 1
  * bias-free layers y = act(x W^T), fp16 storage / fp32 accumulation, one d3d_gemm_nt launch per layer with the activation in
  * the epilogue.  x (n_rows, n_in) f16; weights: HOST array of n_hidden + 1 device pointers, layer l row-major (out_l, in_l)

@@ -15,8 +15,12 @@ from .ff_oracle import FeatureFieldsOracle
 
 
 class StepOracle:
-    def __init__(self, sd: Dict[str, torch.Tensor], vit_cfg, llm_cfg, batch_size: int, tokenizer, depth_scale=(0.0, 10.0)):
+    def __init__(self, sd: Dict[str, torch.Tensor], vit_cfg, llm_cfg, batch_size: int, tokenizer, depth_scale=(0.0, 10.0),
+                 clip_dtype=torch.float32, llava_dtype=torch.float32):
+        """clip_dtype / llava_dtype: evaluate the towers the way the reference does in those dtypes (towers_ref `lowp`)."""
         self.sd, self.vit, self.llm, self.tok = sd, vit_cfg, llm_cfg, tokenizer
+        self.clip_lowp = None if clip_dtype == torch.float32 else clip_dtype
+        self.lm_lowp = None if llava_dtype == torch.float32 else llava_dtype
         self.ff = FeatureFieldsOracle(sd, batch_size)
         self.history = [["none\n"] * 4 for _ in range(batch_size)]
         self.depth_scale = depth_scale
@@ -28,7 +32,7 @@ class StepOracle:
         t0 = time.time()
         d24 = G.preprocess_depth(G.downsample_depth_nearest(depth), self.depth_scale).reshape(B, 1, -1)     # VLN-POL:336-341 (F9 fixed)
         px = TR.preprocess_rgb(rgb, self.vit.image)
-        _, grid = TR.clip_vit_forward(px, self.sd, self.vit.layers, self.vit.heads, self.vit.patch)         # VLN-POL:344
+        _, grid = TR.clip_vit_forward(px, self.sd, self.vit.layers, self.vit.heads, self.vit.patch, lowp=self.clip_lowp)   # VLN-POL:344
         t1 = time.time()
         dfull = G.preprocess_depth(depth, self.depth_scale)[..., 0]
         self.ff.delete_old_features_from_camera_frustum(dfull.reshape(B, 1, *dfull.shape[1:]), positions, headings)   # VLN-POL:351
@@ -39,20 +43,23 @@ class StepOracle:
         info6 = torch.cat([rx, ry, rz, torch.sin(dr), torch.cos(dr), sc], -1)
         cat = lambda xs, w: torch.from_numpy(np.concatenate(xs).reshape(-1, w).astype(np.float32))
         patch_pos, inst_tok, zone_tok = TR.prefix_tokens(info6, cat(env["batch_instance_fts"], 768), cat(env["batch_instance_relative_position"], 3),
-                                                         cat(env["batch_zone_fts"], 768), cat(env["batch_zone_relative_position"], 3), self.sd)
+                                                         cat(env["batch_zone_fts"], 768), cat(env["batch_zone_relative_position"], 3), self.sd,
+                                                         lowp=self.lm_lowp)
         t2 = time.time()
-        patch_tok = TR.llava_image_features(px, self.sd, self.vit.layers, self.vit.heads, self.vit.patch) + patch_pos       # VLN-POL:448-453
+        R = TR._rounder(self.lm_lowp)
+        patch_tok = R(TR.llava_image_features(px, self.sd, self.vit.layers, self.vit.heads, self.vit.patch, lowp=self.lm_lowp) + patch_pos)   # VLN-POL:448-453
         t3 = time.time()
-        emb_w = self.sd["language_model.model.embed_tokens.weight"].float()
-        head = emb_w[torch.tensor(self.tok.encode("<|user|>", bos=True))]
+        emb_w = R(self.sd["language_model.model.embed_tokens.weight"].float())
         ni = [len(x) for x in env["batch_instance_fts"]]
         nz = [len(x) for x in env["batch_zone_fts"]]
         io, zo = np.concatenate([[0], np.cumsum(ni)]), np.concatenate([[0], np.cumsum(nz)])
         rows = []
         for b in range(B):
-            text = ("\nInstruction:\n" + instructions[b] + "\nHistory actions:\n" + "".join(self.history[b]) + "<|end|>\n<|assistant|>\nNext action:\n")
-            te = emb_w[torch.tensor(self.tok.encode(text))]
-            rows.append(torch.cat([head, patch_tok[b], inst_tok[io[b]:io[b + 1]], zone_tok[zo[b]:zo[b + 1]], te], 0))     # VLN-POL:456
+            n_vis = patch_tok.shape[1] + ni[b] + nz[b]
+            text = ("<|user|>\n" + "<image>" * n_vis + "\nInstruction:\n" + instructions[b] + "\nHistory actions:\n" + "".join(self.history[b])
+                    + "<|end|>\n<|assistant|>\nNext action:\n")                                                   # VLN-POL:436
+            e = emb_w[torch.tensor(self.tok.encode(text))]                                                       # VLN-POL:438-439
+            rows.append(torch.cat([e[:2], patch_tok[b], inst_tok[io[b]:io[b + 1]], zone_tok[zo[b]:zo[b + 1]], e[n_vis + 2:]], 0))   # VLN-POL:456
         lengths = [r.shape[0] for r in rows]
         emb = torch.zeros(B, max(lengths), emb_w.shape[1])
         for b, r in enumerate(rows):
@@ -62,11 +69,21 @@ class StepOracle:
         return emb, lengths
 
     @torch.no_grad()
+    def advance_memory(self, depth: np.ndarray, positions, headings, patch_segm, grid: np.ndarray):
+        """One step of the 3D memory only (frustum delete + update, VLN-POL:349-354) on GIVEN CLIP grid features (B,576,768): brings
+        the memory to a warm operating point without running the towers (bench.py's cpu_baseline)."""
+        B = depth.shape[0]
+        d24 = G.preprocess_depth(G.downsample_depth_nearest(depth), self.depth_scale).reshape(B, 1, -1)
+        dfull = G.preprocess_depth(depth, self.depth_scale)[..., 0]
+        self.ff.delete_old_features_from_camera_frustum(dfull.reshape(B, 1, *dfull.shape[1:]), positions, headings)
+        self.ff.update_feature_fields(d24, np.asarray(grid, np.float32).reshape(B, 1, *grid.shape[1:]), patch_segm, positions, headings)
+
+    @torch.no_grad()
     def forward_logits(self, rgb, depth, instructions, positions, headings, patch_segm) -> np.ndarray:
         emb, lengths = self.build_inputs(rgb, depth, instructions, positions, headings, patch_segm)
         t0 = time.time()
         c = self.llm
-        lo = TR.phi3_prefill_logits(emb, lengths, self.sd, c.layers, c.heads, c.kv_heads, c.rms_eps, c.rope_theta)
+        lo = TR.phi3_prefill_logits(emb, lengths, self.sd, c.layers, c.heads, c.kv_heads, c.rms_eps, c.rope_theta, lowp=self.lm_lowp)
         self.timing["phi3_prefill"] = time.time() - t0
         self.last_embeds, self.last_lengths = emb, lengths
         return lo.numpy()
@@ -79,7 +96,8 @@ class StepOracle:
         emb, lengths = self.build_inputs(rgb, depth, instructions, positions, headings, patch_segm)
         c = self.llm
         end_id = self.tok.SPECIAL["<|end|>"] % c.vocab
-        toks, _ = TR.phi3_greedy_decode(emb, lengths, self.sd, c.layers, c.heads, c.kv_heads, max_new_tokens, end_id, c.rms_eps, c.rope_theta)
+        toks, _ = TR.phi3_greedy_decode(emb, lengths, self.sd, c.layers, c.heads, c.kv_heads, max_new_tokens, end_id, c.rms_eps, c.rope_theta,
+                                        lowp=self.lm_lowp)
         self.last_tokens = toks
         texts = []
         for b, ids in enumerate(toks):

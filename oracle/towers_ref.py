@@ -10,6 +10,12 @@ oracle/geometry.py header).
                              installed transformers' Phi3ForCausalLM on seeded small configs
   * prefix MLPs / splice  <- VLN-POL:432-461
 Pinning scripts: tests/golden/gen_golden_dense.py (goldens g5, g8, g9).
+
+`lowp=torch.float16 / torch.bfloat16` evaluates the SAME restatement the way the reference evaluates its modules in
+its own dtypes (OpenAI CLIP after `convert_weights` in fp16, clip/model.py:373-395; llava / Phi-3 with
+`torch_dtype=torch.bfloat16`, VLN-POL:125): float32 arithmetic inside a module, a 16-bit store at every module
+output (Linear, activation, residual add, norm, rotary products, softmax @ V), parameters rounded to the dtype
+they are held in.  Pinned by tests/golden/gen_golden_lowp.py (g11-g14: the real modules run in those dtypes).
 """
 from __future__ import annotations
 
@@ -38,48 +44,62 @@ def preprocess_rgb(rgb_u8: np.ndarray, size: int = 336) -> T:
     return (x - m) / s
 
 
-def _vit_blocks(x: T, get, n_layers: int, heads: int) -> T:
-    """Pre-LN residual blocks with QuickGELU MLP; `get(i, name)` returns the (fused-qkv) tensors."""
+def _rounder(lowp):
+    """R(x): store-and-reload in the module dtype (identity for float32)."""
+    if lowp is None or lowp == torch.float32:
+        return lambda x: x
+    return lambda x: x.to(lowp).float()
+
+
+def _vit_blocks(x: T, get, n_layers: int, heads: int, lowp=None, ln_lowp: bool = False) -> T:
+    """Pre-LN residual blocks with QuickGELU MLP; `get(i, name)` returns the (fused-qkv) tensors.
+    lowp: 16-bit module dtype (see module docstring); ln_lowp: LayerNorm parameters are held in that dtype too
+    (HF `model.to(bfloat16)`) or stay float32 (OpenAI `convert_weights` skips LayerNorm)."""
     B, L, W = x.shape
     hd = W // heads
+    R = _rounder(lowp)
+    Rn = R if ln_lowp else (lambda t: t)
     for i in range(n_layers):
-        h = F.layer_norm(x, (W,), get(i, "ln1_w"), get(i, "ln1_b"), 1e-5)
-        qkv = F.linear(h, get(i, "qkv_w"), get(i, "qkv_b")).view(B, L, 3, heads, hd)
+        h = R(F.layer_norm(x, (W,), Rn(get(i, "ln1_w")), Rn(get(i, "ln1_b")), 1e-5))
+        qkv = R(F.linear(h, R(get(i, "qkv_w")), R(get(i, "qkv_b")))).view(B, L, 3, heads, hd)
         q, k, v = (qkv[:, :, j].transpose(1, 2) for j in range(3))
-        att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)
-        a = (att @ v).transpose(1, 2).reshape(B, L, W)
-        x = x + F.linear(a, get(i, "out_w"), get(i, "out_b"))
-        h = F.layer_norm(x, (W,), get(i, "ln2_w"), get(i, "ln2_b"), 1e-5)
-        h = F.linear(h, get(i, "fc1_w"), get(i, "fc1_b"))
-        h = h * torch.sigmoid(1.702 * h)
-        x = x + F.linear(h, get(i, "fc2_w"), get(i, "fc2_b"))
+        att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)        # fused attention: float32 scores / softmax,
+        a = R(R(att) @ v).transpose(1, 2).reshape(B, L, W)                             # probabilities and the output stored 16-bit
+        x = R(x + R(F.linear(a, R(get(i, "out_w")), R(get(i, "out_b")))))
+        h = R(F.layer_norm(x, (W,), Rn(get(i, "ln2_w")), Rn(get(i, "ln2_b")), 1e-5))
+        h = R(F.linear(h, R(get(i, "fc1_w")), R(get(i, "fc1_b"))))
+        h = R(h * R(torch.sigmoid(R(1.702 * h))))                                      # x * sigmoid(1.702 * x), three stores
+        x = R(x + R(F.linear(h, R(get(i, "fc2_w")), R(get(i, "fc2_b")))))
     return x
 
 
-def _embed(pixels: T, patch_w: T, cls: T, pos: T, patch: int) -> T:
-    x = F.conv2d(pixels, patch_w, stride=patch)
+def _embed(pixels: T, patch_w: T, cls: T, pos: T, patch: int, lowp=None) -> T:
+    R = _rounder(lowp)
+    x = R(F.conv2d(R(pixels), R(patch_w), stride=patch))
     x = x.flatten(2).transpose(1, 2)
-    x = torch.cat([cls.view(1, 1, -1).expand(x.shape[0], 1, -1), x], 1)
-    return x + pos
+    x = torch.cat([R(cls).view(1, 1, -1).expand(x.shape[0], 1, -1), x], 1)
+    return R(x + R(pos))
 
 
-def clip_vit_forward(pixels: T, sd: Dict[str, T], layers: int, heads: int, patch: int = 14):
+def clip_vit_forward(pixels: T, sd: Dict[str, T], layers: int, heads: int, patch: int = 14, lowp=None):
     p = "visual."
     names = dict(ln1_w="ln_1.weight", ln1_b="ln_1.bias", ln2_w="ln_2.weight", ln2_b="ln_2.bias", qkv_w="attn.in_proj_weight",
                  qkv_b="attn.in_proj_bias", out_w="attn.out_proj.weight", out_b="attn.out_proj.bias", fc1_w="mlp.c_fc.weight",
                  fc1_b="mlp.c_fc.bias", fc2_w="mlp.c_proj.weight", fc2_b="mlp.c_proj.bias")
     get = lambda i, n: sd[f"{p}transformer.resblocks.{i}.{names[n]}"].float()
-    x = _embed(pixels, sd[p + "conv1.weight"].float(), sd[p + "class_embedding"].float(), sd[p + "positional_embedding"].float(), patch)
+    R = _rounder(lowp)
+    x = _embed(pixels, sd[p + "conv1.weight"].float(), sd[p + "class_embedding"].float(), sd[p + "positional_embedding"].float(), patch, lowp)
     W = x.shape[-1]
-    x = F.layer_norm(x, (W,), sd[p + "ln_pre.weight"].float(), sd[p + "ln_pre.bias"].float(), 1e-5)
-    x = _vit_blocks(x, get, layers, heads)
-    x = F.layer_norm(x, (W,), sd[p + "ln_post.weight"].float(), sd[p + "ln_post.bias"].float(), 1e-5)
-    y = x @ sd[p + "proj"].float()
+    x = R(F.layer_norm(x, (W,), sd[p + "ln_pre.weight"].float(), sd[p + "ln_pre.bias"].float(), 1e-5))     # LayerNorm stays float32 (model.py:153-159)
+    x = _vit_blocks(x, get, layers, heads, lowp, ln_lowp=False)
+    x = R(F.layer_norm(x, (W,), sd[p + "ln_post.weight"].float(), sd[p + "ln_post.bias"].float(), 1e-5))
+    y = R(x @ R(sd[p + "proj"].float()))
     return y[:, 0], y[:, 1:]
 
 
-def llava_image_features(pixels: T, sd: Dict[str, T], layers: int, heads: int, patch: int = 14, feature_layer: int = -2) -> T:
+def llava_image_features(pixels: T, sd: Dict[str, T], layers: int, heads: int, patch: int = 14, feature_layer: int = -2, lowp=None) -> T:
     v = "vision_tower.vision_model."
+    R = _rounder(lowp)
 
     def get(i, n):
         q = f"{v}encoder.layers.{i}."
@@ -93,37 +113,38 @@ def llava_image_features(pixels: T, sd: Dict[str, T], layers: int, heads: int, p
         return sd[q + m[n]].float()
 
     x = _embed(pixels, sd[v + "embeddings.patch_embedding.weight"].float(), sd[v + "embeddings.class_embedding"].float(),
-               sd[v + "embeddings.position_embedding.weight"].float(), patch)
+               sd[v + "embeddings.position_embedding.weight"].float(), patch, lowp)
     W = x.shape[-1]
-    x = F.layer_norm(x, (W,), sd[v + "pre_layrnorm.weight"].float(), sd[v + "pre_layrnorm.bias"].float(), 1e-5)
-    x = _vit_blocks(x, get, layers + 1 + feature_layer, heads)[:, 1:]
-    h = F.gelu(F.linear(x, sd["multi_modal_projector.linear_1.weight"].float(), sd["multi_modal_projector.linear_1.bias"].float()))
-    return F.linear(h, sd["multi_modal_projector.linear_2.weight"].float(), sd["multi_modal_projector.linear_2.bias"].float())
+    x = R(F.layer_norm(x, (W,), R(sd[v + "pre_layrnorm.weight"].float()), R(sd[v + "pre_layrnorm.bias"].float()), 1e-5))
+    x = _vit_blocks(x, get, layers + 1 + feature_layer, heads, lowp, ln_lowp=True)[:, 1:]
+    h = R(F.gelu(R(F.linear(x, R(sd["multi_modal_projector.linear_1.weight"].float()), R(sd["multi_modal_projector.linear_1.bias"].float())))))
+    return R(F.linear(h, R(sd["multi_modal_projector.linear_2.weight"].float()), R(sd["multi_modal_projector.linear_2.bias"].float())))
 
 
 def phi3_prefill_logits(embeds: T, lengths: Sequence[int], sd: Dict[str, T], layers: int, heads: int, kv_heads: int,
-                        rms_eps: float = 1e-5, theta: float = 10000.0) -> T:
+                        rms_eps: float = 1e-5, theta: float = 10000.0, lowp=None) -> T:
     """embeds (B,S,H) right-padded f32 -> logits (B,vocab) at position lengths[b]-1."""
     m = "language_model.model."
     B, S, H = embeds.shape
     hd = H // heads
+    R = _rounder(lowp)
     inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
     ang = torch.arange(S, dtype=torch.float32)[:, None] * inv[None]
-    cos, sin = torch.cat([ang.cos(), ang.cos()], -1), torch.cat([ang.sin(), ang.sin()], -1)
+    cos, sin = R(torch.cat([ang.cos(), ang.cos()], -1)), R(torch.cat([ang.sin(), ang.sin()], -1))    # HF casts cos / sin to the activations' dtype
 
-    def rms(x, w):
-        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + rms_eps) * w.float()
+    def rms(x, w):           # HF Phi3RMSNorm: weight * x_hat.to(input_dtype)
+        return R(R(w.float()) * R(x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + rms_eps)))
 
-    def rot(x):   # (B,h,S,hd)
+    def rot(x):   # (B,h,S,hd): (x * cos) + (rotate_half(x) * sin), every product stored
         x1, x2 = x[..., : hd // 2], x[..., hd // 2:]
-        return x * cos + torch.cat([-x2, x1], -1) * sin
+        return R(R(x * cos) + R(torch.cat([-x2, x1], -1) * sin))
 
     causal = torch.ones(S, S, dtype=torch.bool).tril()
-    x = embeds.float()
+    x = R(embeds.float())
     for i in range(layers):
         p = f"{m}layers.{i}."
         h = rms(x, sd[p + "input_layernorm.weight"])
-        qkv = F.linear(h, sd[p + "self_attn.qkv_proj.weight"].float())
+        qkv = R(F.linear(h, R(sd[p + "self_attn.qkv_proj.weight"].float())))
         q = qkv[..., : heads * hd].view(B, S, heads, hd).transpose(1, 2)
         k = qkv[..., heads * hd: (heads + kv_heads) * hd].view(B, S, kv_heads, hd).transpose(1, 2)
         v = qkv[..., (heads + kv_heads) * hd:].view(B, S, kv_heads, hd).transpose(1, 2)
@@ -132,30 +153,30 @@ def phi3_prefill_logits(embeds: T, lengths: Sequence[int], sd: Dict[str, T], lay
             k, v = k.repeat_interleave(heads // kv_heads, 1), v.repeat_interleave(heads // kv_heads, 1)
         att = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
         att = torch.softmax(att.masked_fill(~causal, float("-inf")), -1)
-        a = (att @ v).transpose(1, 2).reshape(B, S, heads * hd)
-        x = x + F.linear(a, sd[p + "self_attn.o_proj.weight"].float())
+        a = R(R(att) @ v).transpose(1, 2).reshape(B, S, heads * hd)
+        x = R(x + R(F.linear(a, R(sd[p + "self_attn.o_proj.weight"].float()))))
         h = rms(x, sd[p + "post_attention_layernorm.weight"])
-        gu = F.linear(h, sd[p + "mlp.gate_up_proj.weight"].float())
+        gu = R(F.linear(h, R(sd[p + "mlp.gate_up_proj.weight"].float())))
         g, u = gu.chunk(2, -1)
-        x = x + F.linear(u * F.silu(g), sd[p + "mlp.down_proj.weight"].float())
+        x = R(x + R(F.linear(R(u * R(F.silu(g))), R(sd[p + "mlp.down_proj.weight"].float()))))
     last = x[torch.arange(B), torch.as_tensor(lengths) - 1]
-    return F.linear(rms(last, sd[m + "norm.weight"]), sd["language_model.lm_head.weight"].float())
+    return R(F.linear(rms(last, sd[m + "norm.weight"]), R(sd["language_model.lm_head.weight"].float())))
 
 
 def phi3_greedy_decode(embeds: T, lengths: Sequence[int], sd: Dict[str, T], layers: int, heads: int, kv_heads: int, max_new_tokens: int,
-                       end_id=None, rms_eps: float = 1e-5, theta: float = 10000.0, forced=None):
+                       end_id=None, rms_eps: float = 1e-5, theta: float = 10000.0, forced=None, lowp=None):
     """Greedy generation by DEFINITION -- `llava.generate(inputs_embeds=..., max_new_tokens=20, do_sample=False)` at VLN-POL:463
     (transformers GenerationMixin greedy search, an un-vendored dependency): at every step the whole prefix is run again through
     `phi3_prefill_logits` (no KV cache), the argmax token's embedding is appended to that sequence.  Small cases only.
     Returns (tokens per sequence up to and including end_id, logits (steps,B,vocab)).  `forced` (steps x B) replaces the argmax."""
-    emb_w = sd["language_model.model.embed_tokens.weight"].float()
+    emb_w = _rounder(lowp)(sd["language_model.model.embed_tokens.weight"].float())
     B, S, H = embeds.shape
     emb = torch.zeros(B, S + max_new_tokens, H)
     emb[:, :S] = embeds.float()
     lens = [int(n) for n in lengths]
     gen, done, steps = [[] for _ in range(B)], [False] * B, []
     for i in range(max_new_tokens):
-        lo = phi3_prefill_logits(emb[:, : max(lens)], lens, sd, layers, heads, kv_heads, rms_eps, theta)
+        lo = phi3_prefill_logits(emb[:, : max(lens)], lens, sd, layers, heads, kv_heads, rms_eps, theta, lowp)
         steps.append(lo)
         nxt = lo.argmax(-1) if forced is None else torch.as_tensor(forced[i])
         for b in range(B):
@@ -170,11 +191,20 @@ def phi3_greedy_decode(embeds: T, lengths: Sequence[int], sd: Dict[str, T], laye
     return gen, torch.stack(steps)
 
 
-def prefix_tokens(info6: T, ifts: T, irel: T, zfts: T, zrel: T, sd: Dict[str, T]):
-    """VLN-POL:432-435.  info6 (N,576,6) = [x,y,z,sin d,cos d,scale]."""
+def prefix_tokens(info6: T, ifts: T, irel: T, zfts: T, zrel: T, sd: Dict[str, T], lowp=None):
+    """VLN-POL:432-435.  info6 (N,576,6) = [x,y,z,sin d,cos d,scale].
+    lowp: the product evaluates the SECOND (LM-width x LM-width) layer of `patch_position_embedding`, `instance_projector` and
+    `zone_projector` as a 16-bit GEMM in the LM's dtype (their outputs become LM-dtype tokens; the reference runs all of these
+    MLPs under fp16 autocast, VLN-TR:385): 16-bit operands and a 16-bit store for that layer, float32 before it."""
     f = {k: v.float() for k, v in sd.items() if k.split(".")[0] in ("patch_position_embedding", "instance_position_embedding",
                                                                      "zone_position_embedding", "instance_projector", "zone_projector")}
-    patch = NN.mlp_ln_gelu(info6, f, "patch_position_embedding")
-    inst = NN.mlp_ln_gelu(torch.cat([ifts, NN.mlp_ln_gelu(irel, f, "instance_position_embedding")], -1), f, "instance_projector")
-    zone = NN.mlp_ln_gelu(torch.cat([zfts, NN.mlp_ln_gelu(zrel, f, "zone_position_embedding")], -1), f, "zone_projector")
+    R = _rounder(lowp)
+
+    def mlp2(x, name):
+        h = F.gelu(NN.layer_norm(NN.linear(x, f, name + ".0"), f, name + ".1", 1e-5))
+        return R(F.linear(R(h), R(f[name + ".3.weight"]), R(f[name + ".3.bias"])))
+
+    patch = mlp2(info6, "patch_position_embedding")
+    inst = mlp2(torch.cat([ifts, NN.mlp_ln_gelu(irel, f, "instance_position_embedding")], -1), "instance_projector")
+    zone = mlp2(torch.cat([zfts, NN.mlp_ln_gelu(zrel, f, "zone_position_embedding")], -1), "zone_projector")
     return patch, inst, zone

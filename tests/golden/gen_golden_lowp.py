@@ -104,6 +104,18 @@ def g12():
     print("g12 %.1fs  bf16 vs f32 rel %.2e" % (time.time() - t0, float((f16.float() - f32).norm() / f32.norm())))
 
 
+def _to_bf16_like_4_46(hf):
+    """`model.to(bfloat16)` of transformers 5.x also casts the rotary `inv_freq` BUFFER to bf16 (angles then come from rounded
+    frequencies).  The reference's pinned transformers 4.46.0 recomputes `inv_freq` in float32 inside every
+    `Phi3RotaryEmbedding.forward`, so its bf16 model rotates with float32 frequencies and bf16-cast cos / sin: restore that."""
+    inv32 = hf.model.rotary_emb.inv_freq.clone().float()
+    hf = hf.to(torch.bfloat16)
+    hf.model.rotary_emb.inv_freq = inv32
+    if hasattr(hf.model.rotary_emb, "original_inv_freq"):
+        hf.model.rotary_emb.original_inv_freq = inv32
+    return hf
+
+
 def g13():
     import transformers
     from transformers import Phi3Config as HFPhi3Config, Phi3ForCausalLM
@@ -122,7 +134,7 @@ def g13():
     with torch.no_grad():
         for r in rows:
             lo32.append(hf(inputs_embeds=r.float()[None]).logits[0, -1].numpy())
-        hf = hf.to(torch.bfloat16)
+        hf = _to_bf16_like_4_46(hf)
         for r in rows:
             lo16.append(hf(inputs_embeds=r[None]).logits[0, -1].float().numpy())
     lo32, lo16 = np.stack(lo32), np.stack(lo16)
@@ -133,7 +145,66 @@ def g13():
     print("g13 %.1fs  bf16 vs f32 rel per row" % (time.time() - t0), np.round(rel, 4), "argmax equal", (lo16.argmax(-1) == lo32.argmax(-1)).tolist())
 
 
+def g14():
+    """Small configurations of the three towers in the reference's dtypes (seconds on the CPU): pins oracle/towers_ref.py's
+    `lowp` mode in the CPU suite."""
+    import transformers
+    from transformers import CLIPVisionConfig, CLIPVisionModel, Phi3Config as HFPhi3Config, Phi3ForCausalLM
+    out = dict(torch=torch.__version__, transformers=transformers.__version__)
+    vit = VitConfig(image=56, patch=14, width=128, layers=3, heads=4, mlp=512, out_dim=96, proj_dim=192)
+    rgb = frames(140, 2, 40)
+    out["rgb"] = rgb
+    px = TR.preprocess_rgb(rgb, vit.image)
+    # OpenAI CLIP, fp16
+    clipm = rh.load_ref_clip()
+    sd = synth_state_dict(clip_param_spec(vit), seed=0)
+    vt = clipm.VisionTransformer(vit.image, vit.patch, vit.width, vit.layers, vit.heads, vit.out_dim).eval()
+    vt.load_state_dict({k[len("visual."):]: v for k, v in sd.items()}, strict=True)
+    with torch.no_grad():
+        _, p32 = vt(px)
+        clipm.convert_weights(vt)
+        _, p16 = vt(px.half())
+    out["clip_f32"], out["clip_f16"] = p32.numpy(), p16.float().numpy()
+    # HF CLIP vision + projector, bf16
+    hf = CLIPVisionModel(CLIPVisionConfig(hidden_size=vit.width, intermediate_size=vit.mlp, num_hidden_layers=vit.layers, num_attention_heads=vit.heads,
+                                          image_size=vit.image, patch_size=vit.patch, hidden_act="quick_gelu", layer_norm_eps=1e-5)).eval()
+    sd = synth_state_dict(llava_vision_param_spec(vit), seed=0)
+    own = {k[len("vision_tower."):]: v for k, v in sd.items() if k.startswith("vision_tower.")}
+    if not any(k.startswith("vision_model.") for k in hf.state_dict()):
+        own = {k[len("vision_model."):]: v for k, v in own.items()}
+    hf.load_state_dict(own, strict=False)
+    w1, b1 = sd["multi_modal_projector.linear_1.weight"], sd["multi_modal_projector.linear_1.bias"]
+    w2, b2 = sd["multi_modal_projector.linear_2.weight"], sd["multi_modal_projector.linear_2.bias"]
+    bf = torch.bfloat16
+    with torch.no_grad():
+        hs = hf(pixel_values=px, output_hidden_states=True).hidden_states[-2][:, 1:]
+        out["llava_f32"] = F.linear(F.gelu(F.linear(hs, w1, b1)), w2, b2).numpy()
+        hf = hf.to(bf)
+        hs = hf(pixel_values=px.to(bf), output_hidden_states=True).hidden_states[-2][:, 1:]
+        out["llava_bf16"] = F.linear(F.gelu(F.linear(hs, w1.to(bf), b1.to(bf))), w2.to(bf), b2.to(bf)).float().numpy()
+    # HF Phi-3, bf16
+    c = Phi3Config(vocab=512, hidden=192, layers=3, heads=6, kv_heads=6, mlp=384)
+    hf = Phi3ForCausalLM(HFPhi3Config(vocab_size=c.vocab, hidden_size=c.hidden, intermediate_size=c.mlp, num_hidden_layers=c.layers,
+                                      num_attention_heads=c.heads, num_key_value_heads=c.kv_heads, rms_norm_eps=c.rms_eps, rope_theta=c.rope_theta,
+                                      max_position_embeddings=c.max_pos, original_max_position_embeddings=c.max_pos, pad_token_id=0,
+                                      tie_word_embeddings=False)).eval()
+    sd = synth_state_dict(phi3_param_spec(c), seed=0)
+    hf.load_state_dict({k[len("language_model."):]: v for k, v in sd.items()}, strict=False)
+    g = torch.Generator().manual_seed(141)
+    lens = [37, 50, 23]
+    emb = (torch.randn(3, 50, c.hidden, generator=g) * 0.5).to(bf)
+    with torch.no_grad():
+        lo32 = np.stack([hf(inputs_embeds=emb[b:b + 1, :L].float()).logits[0, -1].numpy() for b, L in enumerate(lens)])
+        hf = _to_bf16_like_4_46(hf)
+        lo16 = np.stack([hf(inputs_embeds=emb[b:b + 1, :L]).logits[0, -1].float().numpy() for b, L in enumerate(lens)])
+    out.update(phi_embeds=emb.float().numpy(), phi_lengths=np.array(lens), phi_f32=lo32, phi_bf16=lo16)
+    np.savez_compressed(os.path.join(OUT, "g14_lowp_small.npz"), **out)
+    r = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    print("g14 clip fp16 vs f32 %.2e | llava bf16 vs f32 %.2e | phi3 bf16 vs f32 %.2e" %
+          (r(out["clip_f16"], out["clip_f32"]), r(out["llava_bf16"], out["llava_f32"]), r(lo16, lo32)))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for w in (sys.argv[1:] or ["g11", "g12", "g13"]):
+    for w in (sys.argv[1:] or ["g11", "g12", "g13", "g14"]):
         globals()[w]()

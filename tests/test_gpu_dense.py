@@ -1,6 +1,9 @@
 """GPU: hand-written dense kernels (GEMM + fused epilogues, LayerNorm/RMSNorm, RoPE, SwiGLU, bicubic front-end)
-against plain PyTorch float32 references of the same op.  Tolerances: outputs are bf16/fp16, i.e. one final
-rounding (unit roundoff 3.9e-3 / 4.9e-4) on top of fp32 accumulation -> relative L2 <= 3e-3 (bf16) / 6e-4 (fp16)."""
+against plain PyTorch float32 references of the same op, evaluated WITH THE REFERENCE'S 16-BIT STORES: a fused kernel must
+return what the module sequence it replaces returns in bf16 / fp16 (include/dynam3d_hip.h "ROUNDING POINTS"), e.g.
+bias+residual = R(R(acc + bias) + residual).  `epi_ref` below spells every epilogue out; with the stores in the same places
+what is left is float32 summation order flipping an occasional store, so the tolerances are a third of a one-rounding bound
+(bf16 1e-3, fp16 2e-4 relative L2; unit round-offs are 3.9e-3 / 4.9e-4) -- a kernel that stored once at the end would fail."""
 import numpy as np
 import pytest
 import torch
@@ -19,7 +22,31 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
+def epi_ref(name, y32, b, r, dt):
+    """The module sequence each fused epilogue replaces, float32 arithmetic with a store in `dt` after every module."""
+    R = lambda t: t.to(dt).float()
+    N = y32.shape[1]
+    bf = None if b is None else b.float()
+    rf = None if r is None else r.float()
+    if name == "none":
+        return R(y32)
+    if name == "bias":
+        return R(y32 + bf)
+    if name == "qgelu":                                   # x * sigmoid(1.702 * x) on 16-bit tensors (clip/model.py:162-164)
+        y = R(y32 + bf)
+        return R(y * R(torch.sigmoid(R(1.702 * y))))
+    if name == "gelu":
+        return R(F.gelu(R(y32 + bf)))
+    if name == "res":
+        return R(R(y32) + rf)
+    if name == "bias_res":
+        return R(R(y32 + bf) + rf)
+    if name == "swiglu":                                  # HF Phi3MLP: up * silu(gate)
+        return R(R(y32[:, N // 2:]) * R(F.silu(R(y32[:, :N // 2]))))
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1e-3), (torch.float16, 2e-4)])
 def test_gemm_epilogues_asymmetric(hd, dt, tol):
     from dynam3d_amd.hip_dense import interleave_gate_up
     torch.manual_seed(1)
@@ -32,24 +59,24 @@ def test_gemm_epilogues_asymmetric(hd, dt, tol):
         r = torch.randn(M, N, device="cuda").to(dt)
         y32 = x.float() @ w.float().t()
         cases = {
-            "none": (hd.linear(x, w, None, None), y32),
-            "bias": (hd.linear(x, w, b, None), y32 + b.float()),
-            "qgelu": (hd.linear(x, w, b, "quick_gelu"), (lambda t: t * torch.sigmoid(1.702 * t))(y32 + b.float())),
-            "gelu": (hd.linear(x, w, b, "gelu"), F.gelu(y32 + b.float())),
-            "res": (hd.linear(x, w, None, None, r), y32 + r.float()),
-            "bias_res": (hd.linear(x, w, b, None, r), y32 + b.float() + r.float()),
-            "swiglu": (hd.linear_swiglu(x, interleave_gate_up(w)), y32[:, N // 2:] * F.silu(y32[:, :N // 2])),
+            "none": (hd.linear(x, w, None, None), epi_ref("none", y32, None, None, dt)),
+            "bias": (hd.linear(x, w, b, None), epi_ref("bias", y32, b, None, dt)),
+            "qgelu": (hd.linear(x, w, b, "quick_gelu"), epi_ref("qgelu", y32, b, None, dt)),
+            "gelu": (hd.linear(x, w, b, "gelu"), epi_ref("gelu", y32, b, None, dt)),
+            "res": (hd.linear(x, w, None, None, r), epi_ref("res", y32, None, r, dt)),
+            "bias_res": (hd.linear(x, w, b, None, r), epi_ref("bias_res", y32, b, r, dt)),
+            "swiglu": (hd.linear_swiglu(x, interleave_gate_up(w)), epi_ref("swiglu", y32, None, None, dt)),
         }
         for name, (got, exp) in cases.items():
             assert got.dtype == dt and got.shape == exp.shape
             assert rel(got.float(), exp) < tol, (name, M, N, K, rel(got.float(), exp))
         # strided A (a column slice of a wider buffer)
         big = (torch.randn(M, K + 64, device="cuda")).to(dt)
-        assert rel(hd.linear(big[:, :K], w, None, None).float(), big[:, :K].float() @ w.float().t()) < tol
+        assert rel(hd.linear(big[:, :K], w, None, None).float(), epi_ref("none", big[:, :K].float() @ w.float().t(), None, None, dt)) < tol
 
 
-@pytest.mark.parametrize("tile", [130, 132, 256, 257])
-@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
+@pytest.mark.parametrize("tile", [130, 132, 256, 257, 259])
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1e-3), (torch.float16, 2e-4)])
 def test_gemm_forced_tile_kernels(hd, dt, tol, tile):
     """Every kernel variant forced explicitly -- 128x128 with a 2- / 4-deep LDS ring (130 / 132), 256x256x64 staggered in
     both step sizes (256 = K-half steps, 257 = whole-K-tile steps): ragged M, fewer K tiles than ring slots, many K tiles,
@@ -66,19 +93,19 @@ def test_gemm_forced_tile_kernels(hd, dt, tol, tile):
             b = (torch.randn(N, device="cuda") * 0.3).to(dt)
             r = torch.randn(M, N, device="cuda").to(dt)
             y32 = x.float() @ w.float().t()
-            assert rel(hd.linear(x, w, None, None).float(), y32) < tol, (M, N, K, "none")
-            assert rel(hd.linear(x, w, b, "quick_gelu").float(), (lambda t: t * torch.sigmoid(1.702 * t))(y32 + b.float())) < tol, (M, N, K, "qgelu")
-            assert rel(hd.linear(x, w, b, None, r).float(), y32 + b.float() + r.float()) < tol, (M, N, K, "bias_res")
-            assert rel(hd.linear_swiglu(x, interleave_gate_up(w)).float(), y32[:, N // 2:] * F.silu(y32[:, :N // 2])) < tol, (M, N, K, "swiglu")
+            assert rel(hd.linear(x, w, None, None).float(), epi_ref("none", y32, None, None, dt)) < tol, (M, N, K, "none")
+            assert rel(hd.linear(x, w, b, "quick_gelu").float(), epi_ref("qgelu", y32, b, None, dt)) < tol, (M, N, K, "qgelu")
+            assert rel(hd.linear(x, w, b, None, r).float(), epi_ref("bias_res", y32, b, r, dt)) < tol, (M, N, K, "bias_res")
+            assert rel(hd.linear_swiglu(x, interleave_gate_up(w)).float(), epi_ref("swiglu", y32, None, None, dt)) < tol, (M, N, K, "swiglu")
     finally:
         HipDense.TILE = 0
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1e-3), (torch.float16, 2e-4)])
 def test_gemm_split_k_tail(hd, dt, tol):
-    """Tile code 258: whole rounds of 256x256 tiles data-parallel + the remainder tiles cut into K-slices whose last arriver
-    reduces them in slice order.  Shapes: tail only (4, 44, 100 tiles -> 8, 5, 2 slices), rounds + tail, slices > K tiles,
-    no tail at all; repeated launches reuse the counters; results are bit-identical from launch to launch."""
+    """Tile code 258: whole rounds of 256x256 tiles data-parallel + the remainder tiles cut into K-slices whose fp32 partials a
+    second launch sums in slice order.  Shapes: tail only (4, 44, 100 tiles -> 8, 5, 2 slices), rounds + tail, slices > K tiles,
+    no tail at all; repeated launches reuse the workspace; results are bit-identical from launch to launch."""
     from dynam3d_amd.hip_dense import HipDense, interleave_gate_up
     torch.manual_seed(3)
     try:
@@ -92,15 +119,15 @@ def test_gemm_split_k_tail(hd, dt, tol):
             r = torch.randn(M, N, device="cuda").to(dt)
             y32 = x.float() @ w.float().t()
             for rep in range(2):
-                assert rel(hd.linear(x, w, None, None).float(), y32) < tol, (M, N, K, "none")
-                assert rel(hd.linear(x, w, b, None, r).float(), y32 + b.float() + r.float()) < tol, (M, N, K, "bias_res")
-                assert rel(hd.linear_swiglu(x, interleave_gate_up(w)).float(), y32[:, N // 2:] * F.silu(y32[:, :N // 2])) < tol, (M, N, K, "swiglu")
+                assert rel(hd.linear(x, w, None, None).float(), epi_ref("none", y32, None, None, dt)) < tol, (M, N, K, "none")
+                assert rel(hd.linear(x, w, b, None, r).float(), epi_ref("bias_res", y32, b, r, dt)) < tol, (M, N, K, "bias_res")
+                assert rel(hd.linear_swiglu(x, interleave_gate_up(w)).float(), epi_ref("swiglu", y32, None, None, dt)) < tol, (M, N, K, "swiglu")
             assert torch.equal(hd.linear(x, w, None, None, r), hd.linear(x, w, None, None, r))
     finally:
         HipDense.TILE = 0
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1e-3), (torch.float16, 2e-4)])
 def test_gemm_skinny_decode_rows(hd, dt, tol):
     """M <= 16 rows (KV-cache decode) take the weight-streaming kernel: one wave per 32 output columns and K slice, slices reduced
     in slice order by the last arriver.  1 / 8 / 16 rows, the Phi-3 decode shapes (scaled), a vocabulary-sized N, K not a
@@ -116,23 +143,24 @@ def test_gemm_skinny_decode_rows(hd, dt, tol):
         r = torch.randn(M, N, device="cuda").to(dt)
         y32 = x.float() @ w.float().t()
         for rep in range(2):
-            assert rel(hd.linear(x, w, None, None).float(), y32) < tol, (M, N, K, "none")
-            assert rel(hd.linear(x, w, b, None).float(), y32 + b.float()) < tol, (M, N, K, "bias")
-            assert rel(hd.linear(x, w, None, None, r).float(), y32 + r.float()) < tol, (M, N, K, "res")
+            assert rel(hd.linear(x, w, None, None).float(), epi_ref("none", y32, None, None, dt)) < tol, (M, N, K, "none")
+            assert rel(hd.linear(x, w, b, None).float(), epi_ref("bias", y32, b, None, dt)) < tol, (M, N, K, "bias")
+            assert rel(hd.linear(x, w, None, None, r).float(), epi_ref("res", y32, None, r, dt)) < tol, (M, N, K, "res")
             if N % 32 == 0 and (N // 2) % 16 == 0:
-                assert rel(hd.linear_swiglu(x, interleave_gate_up(w)).float(), y32[:, N // 2:] * F.silu(y32[:, :N // 2])) < tol, (M, N, K, "swiglu")
+                assert rel(hd.linear_swiglu(x, interleave_gate_up(w)).float(), epi_ref("swiglu", y32, None, None, dt)) < tol, (M, N, K, "swiglu")
         assert torch.equal(hd.linear(x, w, None, None, r), hd.linear(x, w, None, None, r))
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-3), (torch.float16, 6e-4)])
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1e-3), (torch.float16, 2e-4)])
 def test_norms_rope_swiglu(hd, dt, tol):
     torch.manual_seed(2)
+    R = lambda t: t.to(dt).float()
     for D in (768, 1024, 3072, 4096, 128):
         x = (torch.randn(1001, D, device="cuda") * 2 + 0.3).to(dt)
         w, b = torch.randn(D, device="cuda") * 0.2 + 1, torch.randn(D, device="cuda") * 0.1
-        assert rel(hd.layer_norm(x, w, b, 1e-5).float(), F.layer_norm(x.float(), (D,), w, b, 1e-5)) < tol
-        xf = x.float()
-        assert rel(hd.rms_norm(x, w, 1e-5).float(), xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * w) < tol
+        assert rel(hd.layer_norm(x, w, b, 1e-5).float(), R(F.layer_norm(x.float(), (D,), w, b, 1e-5))) < tol
+        xf = x.float()                                        # HF Phi3RMSNorm: weight * x_hat.to(dtype)
+        assert rel(hd.rms_norm(x, w, 1e-5).float(), R(R(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)) * w)) < tol
     B, S, H, hdm = 3, 50, 6, 96
     qkv = torch.randn(B, S, 3 * H, hdm, device="cuda").to(dt)
     inv = 1.0 / (10000.0 ** (torch.arange(0, hdm, 2, device="cuda").float() / hdm))
@@ -141,12 +169,12 @@ def test_norms_rope_swiglu(hd, dt, tol):
     ref = qkv.clone().float()
     x1, x2 = ref[:, :, :2 * H, :hdm // 2].clone(), ref[:, :, :2 * H, hdm // 2:].clone()
     c, s = cos[None, :, None], sin[None, :, None]
-    ref[:, :, :2 * H] = torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], -1)
+    ref[:, :, :2 * H] = torch.cat([R(R(x1 * c) - R(x2 * s)), R(R(x2 * c) + R(x1 * s))], -1)      # HF apply_rotary_pos_emb on 16-bit tensors
     got = qkv.clone()
     hd.rope_inplace(got.view(B * S, -1), cos, sin, S, 2 * H, hdm)
     assert rel(got.float(), ref) < tol and torch.equal(got[:, :, 2 * H:], qkv[:, :, 2 * H:])
     gu = torch.randn(333, 2 * 8192, device="cuda").to(dt)
-    assert rel(hd.swiglu(gu).float(), gu[:, 8192:].float() * F.silu(gu[:, :8192].float())) < tol
+    assert rel(hd.swiglu(gu).float(), R(gu[:, 8192:].float() * R(F.silu(gu[:, :8192].float())))) < tol
 
 
 def test_resize_normalize_matches_torch_bicubic(hd):

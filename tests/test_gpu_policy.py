@@ -15,6 +15,7 @@ from tests.test_policy_cpu import SMALL, run_policy_vs_oracle
 pytestmark = pytest.mark.gpu
 
 
+
 def test_policy_fp32_matches_oracle():
     from dynam3d_amd.ops import HipOps
     worst = run_policy_vs_oracle(HipOps(), "cuda", SMALL, steps=3, B=2, tol=1e-3)
@@ -27,6 +28,29 @@ def test_policy_reference_dtypes_close_to_oracle():
     cfg = dataclasses.replace(SMALL, clip_dtype=torch.float16, llava_dtype=torch.bfloat16)
     worst = run_policy_vs_oracle(HipOps(), "cuda", cfg, steps=2, B=2, tol=3e-2)
     assert worst < 3e-2
+
+
+def test_policy_strict_hip_towers_match_lowp_oracle():
+    """The whole step with EVERY dense primitive on a HIP kernel (strict mode: a PyTorch fallback raises; MID is the smallest
+    configuration all of whose shapes are HIP-eligible), fp16 CLIP + bf16 llava / Phi-3, beside the step oracle in float32 and in
+    `lowp` mode (the reference's rounding points in those dtypes, oracle/towers_ref.py).  A 16-bit evaluation sits a noise band away
+    from float32 by construction (the lowp-vs-float32 distance, measured here); the HIP path must sit inside BAND x that band of
+    BOTH oracles."""
+    from dynam3d_amd import dense_ops as D
+    from dynam3d_amd.ops import HipOps
+    from tests.test_policy_cpu import MID, run_policy_three_way
+    was = D.STRICT
+    D.strict(True)
+    D.reset_counts()
+    try:
+        d_lowp, d_f32, band = run_policy_three_way(HipOps(), "cuda", MID, steps=2, B=2)
+        c = D.counts()
+    finally:
+        D.strict(was)
+    assert not c["fallback"] and c["hip"]["linear"] > 0 and c["hip"]["attention"] > 0 and c["hip"]["vit_embed"] > 0, c
+    print(f"MID step, strict HIP ({sum(c['hip'].values())} kernel dispatches, 0 fallbacks): vs lowp oracle {d_lowp:.2e}; vs float32 oracle {d_f32:.2e}; "
+          f"lowp oracle vs float32 oracle (band) {band:.2e}")
+    assert d_lowp < 1.25 * band and d_f32 < 1.25 * band, (d_lowp, d_f32, band)
 
 
 def test_phi3_packed_varlen_prefill_matches_oracle():

@@ -15,11 +15,20 @@ SMALL = PolicyConfig(vit=VitConfig(image=336, patch=14, width=64, layers=2, head
                      clip_dtype=torch.float32, llava_dtype=torch.float32)
 
 
-def run_policy_vs_oracle(ops, device, cfg, steps=3, B=2, tol=2e-4, check_embeds=True):
+# The smallest configuration every dense primitive of which is a HIP kernel (strict mode): GEMM N % 128 == 0 and K % 64 == 0, head
+# dims 64 (ViT) and 96 (LM), 16-bit towers.  Used by smoke() and the strict GPU step tests.
+MID = PolicyConfig(vit=VitConfig(image=336, patch=14, width=256, layers=2, heads=4, mlp=512, out_dim=768, proj_dim=384),
+                   llm=Phi3Config(vocab=640, hidden=384, layers=2, heads=4, kv_heads=4, mlp=512),
+                   clip_dtype=torch.float16, llava_dtype=torch.bfloat16)
+
+
+def run_policy_vs_oracle(ops, device, cfg, steps=3, B=2, tol=2e-4, check_embeds=True, lowp_oracle=False):
+    """lowp_oracle: the oracle evaluates the towers in cfg's dtypes with the reference's rounding points (towers_ref `lowp`)."""
     sd = synth_policy_weights(cfg, seed=0)
     net = Dynam3D_VLN(cfg, sd, device=device, batch_size=B, ops=ops, max_steps=steps + 1)
     net.feature_fields.initialize_camera_setting(90.0, 90.0)
-    orc = StepOracle(sd, cfg.vit, cfg.llm, B, SyntheticTokenizer(cfg.llm.vocab))
+    kw = dict(clip_dtype=cfg.clip_dtype, llava_dtype=cfg.llava_dtype) if lowp_oracle else {}
+    orc = StepOracle(sd, cfg.vit, cfg.llm, B, SyntheticTokenizer(cfg.llm.vocab), **kw)
     ep = SyntheticEpisodes(B, seed=3, image_hw=224, depth_hw=224)
     instr = [INSTRUCTION_64] * B
     worst = 0.0
@@ -35,6 +44,33 @@ def run_policy_vs_oracle(ops, device, cfg, steps=3, B=2, tol=2e-4, check_embeds=
         assert r < tol, (t, r)
         assert np.array_equal(lo.argmax(-1), ref.argmax(-1)) or tol > 1e-3
     return worst
+
+
+def run_policy_three_way(ops, device, cfg, steps=2, B=2):
+    """The product in cfg's 16-bit dtypes beside BOTH oracles in lockstep: float32, and `lowp` (the reference's rounding points in
+    cfg's dtypes).  Returns the worst relative-L2 distances (product-lowp, product-float32, lowp-float32): the last one is the noise
+    band a 16-bit evaluation of this network has by construction."""
+    sd = synth_policy_weights(cfg, seed=0)
+    net = Dynam3D_VLN(cfg, sd, device=device, batch_size=B, ops=ops, max_steps=steps + 1)
+    net.feature_fields.initialize_camera_setting(90.0, 90.0)
+    tok = SyntheticTokenizer(cfg.llm.vocab)
+    o32 = StepOracle(sd, cfg.vit, cfg.llm, B, tok)
+    o16 = StepOracle(sd, cfg.vit, cfg.llm, B, tok, clip_dtype=cfg.clip_dtype, llava_dtype=cfg.llava_dtype)
+    ep = SyntheticEpisodes(B, seed=3, image_hw=224, depth_hw=224)
+    instr = [INSTRUCTION_64] * B
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    worst = [0.0, 0.0, 0.0]
+    for t in range(steps):
+        fr = ep.next()
+        pos, hd = [p.tolist() for p in fr.positions], list(fr.headings)
+        obs = {"rgb": torch.from_numpy(fr.rgb), "depth": torch.from_numpy(fr.depth)}
+        lo = net.forward_logits(obs, instr, pos, hd, patch_segm=fr.patch_segm).float().cpu().numpy()
+        r32 = o32.forward_logits(fr.rgb, fr.depth, instr, pos, hd, fr.patch_segm)
+        r16 = o16.forward_logits(fr.rgb, fr.depth, instr, pos, hd, fr.patch_segm)
+        assert net.last_lengths == o32.last_lengths == o16.last_lengths and net.last_counts == o32.counts == o16.counts
+        for i, d in enumerate((rel(lo, r16), rel(lo, r32), rel(r16, r32))):
+            worst[i] = max(worst[i], d)
+    return tuple(worst)
 
 
 def test_policy_host_logic_matches_step_oracle():
