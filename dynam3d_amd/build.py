@@ -21,6 +21,7 @@ HIP_SOURCES = [
     ("geometry_kernels.hip", ["-ffp-contract=off"]),
     ("dense_kernels.hip", ["-ffp-contract=fast"]),
     ("tower_kernels.hip", ["-ffp-contract=off"]),
+    ("train_kernels.hip", ["-ffp-contract=off"]),
     ("gemm_kernels.hip", ["-ffp-contract=fast"]),
     ("attn_kernels.hip", ["-ffp-contract=fast"]),
     ("render_kernels.hip", ["-ffp-contract=off"]),

@@ -40,7 +40,8 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using float4v = __attribute__((ext_vector_type(4))) float;
 
-enum Epi : int { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_QGELU = 2, EPI_BIAS_GELU = 3, EPI_RES = 4, EPI_BIAS_RES = 5, EPI_SWIGLU = 6, EPI_LRELU = 7 };
+enum Epi : int { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_QGELU = 2, EPI_BIAS_GELU = 3, EPI_RES = 4, EPI_BIAS_RES = 5, EPI_SWIGLU = 6, EPI_LRELU = 7,
+                 EPI_LRELU_BWD = 8 };
 
 template <bool BF16>
 __device__ __forceinline__ float4v mfma16(const uint4& a, const uint4& b, float4v c) {
@@ -151,20 +152,57 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 
 // Epilogue for one 16-column MFMA tile of one output row: this lane owns columns n16 + fg*4 .. +3.
 // SWIGLU: `a` is the gate tile, `b` the matching up tile (weights interleaved per 16 rows); output column n16/2.
-// Rounding points = the reference's module boundaries (include/dynam3d_hip.h "ROUNDING POINTS"): r16() is a store-and-reload
-// in the 16-bit dtype on the fp32 register.
+// Rounding points = the reference's module boundaries (include/dynam3d_hip.h "ROUNDING POINTS").  16-bit stores go through the
+// hardware converters (v_cvt_pk_bf16_f32: two values per instruction, round-to-nearest-even, NaN-safe; v_cvt_f16_f32): with one
+// workgroup per CU nothing overlaps the epilogue, and a hand-rolled integer bf16 rounding (6 VALU operations per value, three stores
+// per SwiGLU output) cost gate_up_proj 7 % (543 against 505 us at M = 6912).
 template <bool BF16>
-__device__ __forceinline__ float r16(float f) { return to_f32<BF16>(from_f32<BF16>(f)); }
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    if constexpr (BF16) {
+        uint32_t r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    } else {
+        const __half2 h = __floats2half2_rn(lo, hi);
+        return *reinterpret_cast<const uint32_t*>(&h);
+    }
+}
+
+// store-and-reload of a pair of fp32 registers in the 16-bit dtype
+template <bool BF16>
+__device__ __forceinline__ void r16x2(float& a, float& b) {
+    const uint32_t u = pack2<BF16>(a, b);
+    if constexpr (BF16) {
+        a = __uint_as_float(u << 16);
+        b = __uint_as_float(u & 0xffff0000u);
+    } else {
+        const __half2 h = *reinterpret_cast<const __half2*>(&u);
+        a = __low2float(h);
+        b = __high2float(h);
+    }
+}
+
+template <bool BF16>
+__device__ __forceinline__ void r16x4(float* v) {
+    r16x2<BF16>(v[0], v[1]);
+    r16x2<BF16>(v[2], v[3]);
+}
 
 template <bool BF16, int EPI>
 __device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
                                        const uint16_t* __restrict__ residual, int m, int n16, int fg, int64_t ldc) {
-    uint16_t o[4];
     if constexpr (EPI == EPI_SWIGLU) {
         // HF Phi3MLP: gate_up = linear(x) [16-bit]; up * silu(gate) with silu's result and the product stored 16-bit
+        float g[4] = {a[0], a[1], a[2], a[3]}, u[4] = {b[0], b[1], b[2], b[3]};
+        r16x4<BF16>(g);
+        r16x4<BF16>(u);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = from_f32<BF16>(r16<BF16>(b[r]) * r16<BF16>(act_silu(r16<BF16>(a[r]))));
-        *reinterpret_cast<uint2*>(C + (int64_t)m * ldc + n16 / 2 + fg * 4) = *reinterpret_cast<const uint2*>(o);
+        for (int r = 0; r < 4; ++r) g[r] = act_silu(g[r]);
+        r16x4<BF16>(g);
+        uint2 o;
+        o.x = pack2<BF16>(u[0] * g[0], u[1] * g[1]);
+        o.y = pack2<BF16>(u[2] * g[2], u[3] * g[3]);
+        *reinterpret_cast<uint2*>(C + (int64_t)m * ldc + n16 / 2 + fg * 4) = o;
     } else {
         const int n = n16 + fg * 4;
         float v[4] = {a[0], a[1], a[2], a[3]};
@@ -175,30 +213,43 @@ __device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint1
             for (int r = 0; r < 4; ++r) v[r] += to_f32<BF16>(bp[r]);
         }
         if constexpr (EPI == EPI_BIAS_QGELU) {          // x * sigmoid(1.702 * x) on 16-bit tensors (clip/model.py:162-164)
+            r16x4<BF16>(v);
+            float t[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float x = r16<BF16>(v[r]);
-                const float t = r16<BF16>(1.702f * x);
-                v[r] = x * r16<BF16>(1.0f / (1.0f + __expf(-t)));
-            }
+            for (int r = 0; r < 4; ++r) t[r] = 1.702f * v[r];
+            r16x4<BF16>(t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = 1.0f / (1.0f + __expf(-t[r]));
+            r16x4<BF16>(t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= t[r];
         }
         if constexpr (EPI == EPI_BIAS_GELU) {
+            r16x4<BF16>(v);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_gelu(r16<BF16>(v[r]));
+            for (int r = 0; r < 4; ++r) v[r] = act_gelu(v[r]);
         }
         if constexpr (EPI == EPI_LRELU) {          // tcnn CutlassMLP hidden activation (slope 0.01), PRE-FF:221-243
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.01f * v[r];
         }
+        if constexpr (EPI == EPI_LRELU_BWD) {      // data gradient through the layer BELOW's LeakyReLU: dz = (dz_above W) * act'(h), `residual` = that layer's output h
+            const uint2 hh = *reinterpret_cast<const uint2*>(residual + (int64_t)m * ldc + n);
+            const uint16_t* hp = reinterpret_cast<const uint16_t*>(&hh);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = to_f32<BF16>(hp[r]) > 0.f ? v[r] : 0.01f * v[r];
+        }
         if constexpr (EPI == EPI_RES || EPI == EPI_BIAS_RES) {
             const uint2 rr = *reinterpret_cast<const uint2*>(residual + (int64_t)m * ldc + n);
             const uint16_t* rp = reinterpret_cast<const uint16_t*>(&rr);
+            r16x4<BF16>(v);                                                          // x + linear(...): the linear's output is a 16-bit tensor
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = r16<BF16>(v[r]) + to_f32<BF16>(rp[r]);      // x + linear(...): the linear's output is a 16-bit tensor
+            for (int r = 0; r < 4; ++r) v[r] += to_f32<BF16>(rp[r]);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = from_f32<BF16>(v[r]);
-        *reinterpret_cast<uint2*>(C + (int64_t)m * ldc + n) = *reinterpret_cast<const uint2*>(o);
+        uint2 o;
+        o.x = pack2<BF16>(v[0], v[1]);
+        o.y = pack2<BF16>(v[2], v[3]);
+        *reinterpret_cast<uint2*>(C + (int64_t)m * ldc + n) = o;
     }
 }
 
@@ -913,6 +964,7 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
         D3D_GEMM_CASE(EPI_BIAS_RES)
         D3D_GEMM_CASE(EPI_SWIGLU)
         D3D_GEMM_CASE(EPI_LRELU)
+        D3D_GEMM_CASE(EPI_LRELU_BWD)
     }
 #undef D3D_GEMM_CASE
     d3d_set_error_("d3d_gemm_nt: unknown epilogue");

@@ -24,10 +24,9 @@ __device__ __forceinline__ float ld16(uint16_t v) {
 template <bool BF16>
 __device__ __forceinline__ uint16_t st16(float f) {
     if constexpr (BF16) {
-        uint32_t u = __float_as_uint(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (uint16_t)(u >> 16);
+        uint32_t r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(f));      // hardware RNE (NaN-safe); one VALU operation
+        return (uint16_t)r;
     } else {
         __half h = __float2half_rn(f);
         return *reinterpret_cast<uint16_t*>(&h);

@@ -2,7 +2,13 @@
 VLN-TR:141, scene splits env_utils.py:87-107); nothing is exchanged on the data path.  The only collective is the
 end-of-evaluation metric gather, issued as ONE all_gather of a float32[10] vector (9 metric sums + episode count)
 instead of the reference's barrier + reduce + 9 scalar all_gathers (VLN-TR:389-408, 735-746).  Backend "nccl" is
-RCCL over xGMI on ROCm; "gloo" is used by the CPU tests."""
+RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
+
+Pre-training step (the reference wraps the net in DDP, PRE-TR:356-360, 479-526, 2237-2271): the same three
+collectives, explicit -- `broadcast_int` (rank 0 picks the dataset loop of the iteration), `any_nan_vote` (the loss is all-reduced
+and the step skipped everywhere if it is NaN anywhere) and `all_reduce_gradients`: gradients are flattened into a few large
+buckets (one collective each; per-message latency dominates a ~160 MB gradient set over xGMI's point-to-point links, so few
+large messages, and the reduction is averaged like DDP's)."""
 from __future__ import annotations
 
 import os
@@ -57,6 +63,69 @@ def barrier():
             dist.barrier(device_ids=[torch.cuda.current_device()])      # pin the collective to this rank's GPU
         else:
             dist.barrier()
+
+
+def broadcast_int(value: int, src: int = 0, device="cpu") -> int:
+    """PRE-TR:2239-2244: every rank runs the dataset loop rank `src` drew."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+        dist.broadcast(t, src=src)
+        return int(t[0])
+    return int(value)
+
+
+def any_nan_vote(loss: torch.Tensor) -> bool:
+    """PRE-TR:505-509: SUM all-reduce of the loss value; True = some rank produced NaN -> every rank skips backward / the step."""
+    v = loss.detach().clone().float().reshape(1)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    return bool(torch.isnan(v).any())
+
+
+def all_reduce_gradients(params, bucket_bytes: int = 64 << 20, average: bool = True, nan_to_zero: bool = True):
+    """Data-parallel gradient reduction (DDP's role, PRE-TR:356-360, 512): the gradients of `params` (those that have one) are
+    packed into float32 buckets of ~`bucket_bytes`, each bucket is ONE all_reduce (SUM), divided by the world size and scattered
+    back into `.grad` in place.  `nan_to_zero` applies the reference's per-parameter NaN scrub (PRE-TR:513-515) after the
+    reduction.  Parameters whose grad is None on this rank are treated as zero so that every rank issues the same collectives
+    (the reference's `* 0.` terms exist for the same reason, PRE-FF:1340).  Returns the number of collectives issued."""
+    params = [p for p in params if p.requires_grad]
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    n_coll = 0
+    if not params:
+        return n_coll
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size, n_coll
+        if not bucket:
+            return
+        dev = bucket[0].device
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
+        if world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            n_coll += 1
+            if average:
+                flat /= world
+        if nan_to_zero:
+            flat = torch.nan_to_num(flat, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
+        o = 0
+        for p in bucket:
+            n = p.numel()
+            g = flat[o:o + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            o += n
+        bucket, size = [], 0
+
+    for p in params:
+        bucket.append(p)
+        size += p.numel() * 4
+        if size >= bucket_bytes:
+            flush()
+    flush()
+    return n_coll
 
 
 def shutdown():

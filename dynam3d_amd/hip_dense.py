@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from ._lib import f32, i32, i64, vp
 
-EPI = dict(none=0, bias=1, bias_quick_gelu=2, bias_gelu=3, res=4, bias_res=5, swiglu=6, lrelu=7)
+EPI = dict(none=0, bias=1, bias_quick_gelu=2, bias_gelu=3, res=4, bias_res=5, swiglu=6, lrelu=7, lrelu_bwd=8)
 
 _lib.register("d3d_gemm_nt", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, vp])
 _lib.register("d3d_gemm_nt_tile", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32, vp])

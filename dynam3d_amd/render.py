@@ -47,8 +47,14 @@ class FieldRenderer:
         self.agg_w, self.agg_b = h("aggregate_patch_to_nerf_encoder.0.weight"), h("aggregate_patch_to_nerf_encoder.0.bias")
         self.agg_ln = (f("aggregate_patch_to_nerf_encoder.1.weight"), f("aggregate_patch_to_nerf_encoder.1.bias"))
         cfg = lambda out_act, nh: {"otype": "CutlassMLP", "activation": "LeakyReLU", "output_activation": out_act, "n_neurons": width, "n_hidden_layers": nh}
-        self.encoder = Network(width, width + 1, cfg("LeakyReLU", 2), [sd[f"nerf_encoder.layers.{i}.weight"] for i in range(3)], device)
-        self.decoder = Network(width, width, cfg("None", 2), [sd[f"nerf_decoder.layers.{i}.weight"] for i in range(3)], device)
+        def net(name, n_out, out_act):
+            # a tinycudann checkpoint holds ONE flat `<name>.params` (PRE-FF:221-243); the harness / synthetic weights use per-layer matrices
+            if name + ".params" in sd:
+                return Network.from_flat_params(width, n_out, cfg(out_act, 2), sd[name + ".params"], device=device)
+            return Network(width, n_out, cfg(out_act, 2), [sd[f"{name}.layers.{i}.weight"] for i in range(3)], device)
+        self.encoder, self.decoder = net("nerf_encoder", width + 1, "LeakyReLU"), net("nerf_decoder", width, "None")
+        for m in (self.encoder, self.decoder):
+            m.requires_grad_(False)                                 # the renderer is the inference path: one C call per network
         # ray tables (PRE-FF:408-422): float64 linspace, float32 tangents
         R = self.H * self.W
         hW, hH = self.W // 2, self.H // 2

@@ -224,7 +224,7 @@ int32_t d3d_gemm_nt(const void* A_d, const void* W_d, void* C_d, const void* bia
  * partials to a library-owned per-stream workspace and a second launch on the same stream sums them in slice order
  * (deterministic) and runs the epilogue -- no workgroup waits for another one, any number of streams / processes may share
  * the GPU.  259 = experiment (LDS-DMA of W issued between the MFMAs).  d3d_gemm_nt picks a tile (and splits the M remainder)
- * itself.  epilogue 7 = LeakyReLU(0.01) for the tcnn CutlassMLP replacement. */
+ * itself.  epilogue 7 = LeakyReLU(0.01) for the tcnn CutlassMLP replacement; 8 = its backward factor (see d3d_lrelu_bwd below). */
 int32_t d3d_gemm_nt_tile(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
                          int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
                          int32_t tile, void* stream);
@@ -239,6 +239,17 @@ int32_t d3d_gemm_reserve_workspace(void* stream);
 int32_t d3d_mlp768_forward(const void* x_d, int64_t n_rows, int32_t n_in, const void* const* weights, int32_t n_hidden,
                            int32_t n_neurons, int32_t n_out_padded, int32_t act, int32_t out_act, void* scratch_a_d,
                            void* scratch_b_d, void* y_d, void* stream);
+/* ---- backward pass of the tcnn CutlassMLP replacement (the Pretrain path trains these networks, PRE-FF:221-243) ----
+ * All three GEMMs of a layer are d3d_gemm_nt launches on 16-bit operands:
+ *   forward        h_l  = act(h_{l-1} W_l^T)                         epilogue 0 / 7
+ *   data gradient  dz_{l-1} = (dz_l W_l) * act'(h_{l-1})             A = dz_l (M,N_l), W = W_l^T stored (K_l,N_l), epilogue 8 with
+ *                                                                    residual_d = h_{l-1} (the output whose sign gates the slope)
+ *   weight gradient dW_l = dz_l^T h_{l-1}                            A = dz_l^T (N_l,Mp), W = h_{l-1}^T (K_l,Mp): d3d_transpose_pad16 */
+int32_t d3d_transpose_pad16(const void* in_d /* (R,C), row stride ld_in */, void* out_d /* (C,Rp), columns [R,Rp) zero */, int32_t R, int32_t C,
+                            int64_t ld_in, int32_t Rp /* % 64, >= R */, void* stream);
+/* dz = dy * (y > 0 ? 1 : 0.01) over n 16-bit elements (n % 8 == 0): LeakyReLU(0.01) backward from the layer's OUTPUT y */
+int32_t d3d_lrelu_bwd(const void* dy_d, const void* y_d, void* dz_d, int64_t n, int32_t dtype, void* stream);
+
 /* One KV-cache decode token through the whole Phi-3 stack (HF Phi3DecoderLayer x n_layers + final norm + lm_head under
  * `llava.generate`, VLN-POL:463), every launch issued from C++.  All pointers are device pointers except the per-layer pointer
  * ARRAYS, which are host arrays of device pointers.  gate_up weights in the per-16 interleaved row order of epilogue 6;

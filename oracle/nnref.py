@@ -66,3 +66,15 @@ def encode_set(tokens: T, cls: T, sd: Dict[str, T], name: str) -> T:
     """[CLS; tokens] -> encoder -> row 0.  tokens (n,768), cls (1,768) -> (1,768)."""
     seq = torch.cat([cls, tokens], dim=0).unsqueeze(0)
     return encoder_post_ln(seq, sd, name)[0, 0:1]
+
+
+def tcnn_mlp(x: T, weights, act: str = "LeakyReLU", out_act: str = "None") -> T:
+    """tinycudann CutlassMLP as used at PRE-FF:221-243: bias-free layers y = act(x W^T), LeakyReLU slope 0.01 (tiny-cuda-nn's
+    `leaky_relu`), differentiable (plain torch ops) -- the float32 restatement the HIP forward / backward are checked against."""
+    h = x
+    for i, w in enumerate(weights):
+        h = F.linear(h, w)
+        a = out_act if i == len(weights) - 1 else act
+        if a == "LeakyReLU":
+            h = F.leaky_relu(h, 0.01)
+    return h

@@ -38,3 +38,60 @@ def test_two_rank_metric_gather(tmp_path):
         assert o["res"]["episodes"] == 5.0
         # sums: rank0 -> (i+1), rank1 -> 2(i+1); mean over 5 episodes
         assert abs(o["res"]["steps_taken"] - 3.0 / 5.0) < 1e-6 and abs(o["res"]["sdtw"] - 27.0 / 5.0) < 1e-6
+
+
+TRAIN_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch
+from dynam3d_amd import dist as D
+rank, local, world = D.init_from_env("gloo")
+torch.manual_seed(0)                                                # identical initial parameters on every rank (DDP's broadcast)
+net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.GELU(), torch.nn.Linear(16, 3))
+extra = torch.nn.Parameter(torch.ones(5))                           # never used on rank 1: its grad is None there
+ds = D.broadcast_int(3 if rank == 0 else 99, src=0)                 # PRE-TR:2239-2244
+g = torch.Generator().manual_seed(100 + rank)                       # different data per rank
+x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+loss = ((net(x) - y) ** 2).mean() + (extra.sum() * 0.5 if rank == 0 else 0.0)
+skip = D.any_nan_vote(loss)
+loss.backward()
+n = D.all_reduce_gradients(list(net.parameters()) + [extra], bucket_bytes=256)     # tiny buckets -> several collectives
+nan_loss = loss * float("nan") if rank == 1 else loss
+skip_nan = D.any_nan_vote(nan_loss)                                 # one rank NaN -> everyone skips (PRE-TR:505-509)
+D.barrier()
+flat = torch.cat([p.grad.reshape(-1) for p in list(net.parameters()) + [extra]])
+print("RESULT", json.dumps(dict(rank=rank, ds=ds, skip=skip, skip_nan=skip_nan, n=n, grad=flat.tolist(), x=x.tolist(), y=y.tolist())))
+"""
+
+
+def test_two_rank_gradient_all_reduce_broadcast_and_nan_vote(tmp_path):
+    """The pre-training step's collectives (PRE-TR:479-526, 2237-2271) over gloo, world 2: the averaged bucketed gradient equals the
+    gradient of the mean loss over both ranks' batches computed in one process."""
+    import json
+    import torch
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    w = tmp_path / "tw.py"
+    w.write_text(TRAIN_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(w), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        o, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, o
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("RESULT")][0][7:]))
+    outs.sort(key=lambda d: d["rank"])
+    assert [o["ds"] for o in outs] == [3, 3] and not any(o["skip"] for o in outs) and all(o["skip_nan"] for o in outs)
+    assert outs[0]["n"] == outs[1]["n"] and outs[0]["n"] >= 2                      # same collectives on both ranks, bucketed
+    assert outs[0]["grad"] == outs[1]["grad"]                                        # identical after the reduction
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.GELU(), torch.nn.Linear(16, 3))
+    extra = torch.nn.Parameter(torch.ones(5))
+    total = 0.0
+    for o in outs:
+        x, y = torch.tensor(o["x"]), torch.tensor(o["y"])
+        total = total + ((net(x) - y) ** 2).mean() + (extra.sum() * 0.5 if o["rank"] == 0 else 0.0)
+    (total / 2).backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in list(net.parameters()) + [extra]])
+    assert torch.allclose(torch.tensor(outs[0]["grad"]), ref, atol=1e-6, rtol=1e-5)

