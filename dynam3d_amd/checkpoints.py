@@ -45,10 +45,24 @@ def load_safetensors_dir(path: str, wanted_prefixes: Iterable[str] = ("language_
     for f in files:
         with safe_open(f, framework="pt", device="cpu") as sf:
             for k in sf.keys():
-                kk = k[len("model."):] if k.startswith("model.") and k[len("model."):].startswith(wanted) else k     # newer HF layouts nest one level
+                kk = canonical_llava_key(k)
                 if kk.startswith(wanted):
                     out[kk] = sf.get_tensor(k)
     return out
+
+
+def canonical_llava_key(k: str) -> str:
+    """Checkpoint key -> the transformers-4.46 llava layout the parameter spec uses (`language_model.model.layers.*`,
+    `language_model.lm_head.weight`, `vision_tower.vision_model.*`, `multi_modal_projector.*`).  transformers >= 4.52 saves
+    LlavaForConditionalGeneration as `model.language_model.layers.*` (the inner `.model` level is gone), `model.vision_tower.*`,
+    `model.multi_modal_projector.*` and a top-level `lm_head.weight`."""
+    if k == "lm_head.weight":
+        return "language_model.lm_head.weight"
+    if k.startswith("model.language_model."):
+        return "language_model.model." + k[len("model.language_model."):]
+    if k.startswith(("model.vision_tower.", "model.multi_modal_projector.")):
+        return k[len("model."):]
+    return k
 
 
 def load_clip_pt(path: str) -> Dict[str, torch.Tensor]:
@@ -78,7 +92,7 @@ def load_dynam3d_pth(path: str) -> Dict[str, torch.Tensor]:
         kk = _strip(k, FF_PREFIXES)
         if kk is None:
             kk = k if not k.startswith(NET_PREFIXES) else None
-        if kk is None or kk.startswith(FF_IGNORED) or any(t in kk for t in FF_IGNORED):
+        if kk is None or kk.startswith(FF_IGNORED):
             continue
         out[kk] = v
     return out
@@ -92,7 +106,7 @@ def load_trainer_ckpt(path: str) -> Dict[str, torch.Tensor]:
     for k, v in sd.items():
         ff = _strip(k, FF_PREFIXES)
         if ff is not None:
-            if not (ff.startswith(FF_IGNORED) or any(t in ff for t in FF_IGNORED)):
+            if not ff.startswith(FF_IGNORED):
                 out[ff] = v
             continue
         kk = _strip(k, NET_PREFIXES) or k

@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -88,7 +89,10 @@ void lowest_unused(const Flags& used, int64_t n_used_domain, int32_t want, std::
 
 }  // namespace
 
+// One handle = the bookkeeping of one Feature_Fields object.  Every entry point takes the handle's mutex, so a handle may be shared by
+// threads (calls are serialised; distinct handles never contend).
 struct d3d_ff {
+    mutable std::mutex mu;
     int32_t compat_fixed = 0, P = 576, K = 2;
     std::vector<Env> env;
     Cell tomb_cell{-5000, -5000, -5000};
@@ -112,25 +116,32 @@ d3d_ff* d3d_ff_create(int32_t compat_fixed, int32_t patches_per_view, int32_t nu
 void d3d_ff_destroy(d3d_ff* ff) { delete ff; }
 
 int32_t d3d_ff_set_tomb_cell(d3d_ff* ff, int32_t cx, int32_t cy, int32_t cz) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     ff->tomb_cell = Cell{cx, cy, cz};
     return D3D_OK;
 }
 
 int32_t d3d_ff_reset(d3d_ff* ff, int32_t batch_size) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     if (batch_size < 0) return fail(D3D_EINVAL, "reset: negative batch");
     ff->env.assign((size_t)batch_size, Env());
     return D3D_OK;
 }
 
 int32_t d3d_ff_pop(d3d_ff* ff, int32_t e) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     if (e < 0 || e >= (int32_t)ff->env.size()) return fail(D3D_EINVAL, "pop: bad env index");
     ff->env.erase(ff->env.begin() + e);
     return D3D_OK;
 }
 
-int32_t d3d_ff_batch_size(const d3d_ff* ff) { return (int32_t)ff->env.size(); }
+int32_t d3d_ff_batch_size(const d3d_ff* ff) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
+    return (int32_t)ff->env.size();
+}
 
 int64_t d3d_ff_count(const d3d_ff* ff, int32_t e, int32_t which) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     if (e < 0 || e >= (int32_t)ff->env.size()) return -1;
     const Env& v = ff->env[e];
     switch (which) {
@@ -147,6 +158,7 @@ int64_t d3d_ff_count(const d3d_ff* ff, int32_t e, int32_t which) {
 
 int32_t d3d_ff_apply_hits(d3d_ff* ff, int32_t e, const int32_t* hits, int32_t n_hits, int32_t* dead_inst,
                           int32_t* n_dead_inst, int32_t* dead_zone, int32_t* n_dead_zone, int32_t cap) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     if (e < 0 || e >= (int32_t)ff->env.size()) return fail(D3D_EINVAL, "apply_hits: bad env");
     Env& v = ff->env[e];
     int32_t ni = 0, nz = 0;
@@ -185,6 +197,7 @@ int32_t d3d_ff_apply_hits(d3d_ff* ff, int32_t e, const int32_t* hits, int32_t n_
 }
 
 int32_t d3d_ff_begin_view(d3d_ff* ff, int32_t e, int32_t* row_base, int32_t* k0, int32_t* has_tree) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     if (e < 0 || e >= (int32_t)ff->env.size()) return fail(D3D_EINVAL, "begin_view: bad env");
     Env& v = ff->env[e];
     *row_base = (int32_t)v.n_rows;
@@ -199,6 +212,7 @@ int32_t d3d_ff_plan_merge(d3d_ff* ff, int32_t e, const int32_t* segm, int32_t n_
                           const float* d2, const int32_t* idx, const float* logits, const int32_t* new_cells,
                           int32_t* k_eff_out, int32_t* seg_slot, int32_t* dirty_inst, int32_t* n_dirty,
                           int32_t* dirty_off, int32_t* dirty_rows, int32_t rows_cap) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     if (e < 0 || e >= (int32_t)ff->env.size()) return fail(D3D_EINVAL, "plan_merge: bad env");
     Env& v = ff->env[e];
     const int32_t P = ff->P;
@@ -300,6 +314,7 @@ int32_t d3d_ff_plan_merge(d3d_ff* ff, int32_t e, const int32_t* segm, int32_t n_
 
 int32_t d3d_ff_plan_zones(d3d_ff* ff, int32_t e, const int32_t* dirty_cells, int32_t* n_touched, int32_t* zone_row,
                           int32_t* zone_mode, int32_t* zone_off, int32_t* zone_members, int32_t zcap, int32_t mcap) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     if (e < 0 || e >= (int32_t)ff->env.size()) return fail(D3D_EINVAL, "plan_zones: bad env");
     Env& v = ff->env[e];
     for (size_t i = 0; i < v.dirty.size(); ++i)
@@ -354,6 +369,7 @@ int32_t d3d_ff_plan_zones(d3d_ff* ff, int32_t e, const int32_t* dirty_cells, int
 }
 
 int32_t d3d_ff_end_view(d3d_ff* ff, int32_t e, int32_t* tree_slots) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     if (e < 0 || e >= (int32_t)ff->env.size()) return fail(D3D_EINVAL, "end_view: bad env");
     Env& v = ff->env[e];
     v.has_tree = v.n_slots > 0;  // get_instance_tree: [] when there are no slots (VLN-FF:243-247)
@@ -362,10 +378,11 @@ int32_t d3d_ff_end_view(d3d_ff* ff, int32_t e, int32_t* tree_slots) {
     return D3D_OK;
 }
 
-int32_t d3d_ff_rebuild_tree(d3d_ff* ff, int32_t e, int32_t* tree_slots) { return d3d_ff_end_view(ff, e, tree_slots); }
+int32_t d3d_ff_rebuild_tree(d3d_ff* ff, int32_t e, int32_t* tree_slots) { return d3d_ff_end_view(ff, e, tree_slots); }   // (locks inside)
 
 int32_t d3d_ff_live_ids(const d3d_ff* ff, int32_t e, int32_t* inst_ids, int32_t* n_inst, int32_t* zone_ids,
                         int32_t* n_zone, int32_t cap) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     if (e < 0 || e >= (int32_t)ff->env.size()) return fail(D3D_EINVAL, "live_ids: bad env");
     const Env& v = ff->env[e];
     std::vector<std::pair<uint64_t, int32_t>> o;
@@ -386,6 +403,7 @@ int32_t d3d_ff_live_ids(const d3d_ff* ff, int32_t e, int32_t* inst_ids, int32_t*
 }
 
 int32_t d3d_ff_export_owner(const d3d_ff* ff, int32_t e, int32_t* owner, int64_t n) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     const Env& v = ff->env[e];
     if (n < (int64_t)v.owner.size()) return fail(D3D_ECAP, "export_owner: buffer too small");
     std::memcpy(owner, v.owner.data(), v.owner.size() * sizeof(int32_t));
@@ -394,6 +412,7 @@ int32_t d3d_ff_export_owner(const d3d_ff* ff, int32_t e, int32_t* owner, int64_t
 
 int32_t d3d_ff_export_members(const d3d_ff* ff, int32_t e, int32_t which, int32_t* ids, int32_t* off, int32_t* flat,
                               int64_t flat_cap) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     const Env& v = ff->env[e];
     const auto& lv = which == 0 ? v.live : v.zlive;
     const auto& st = which == 0 ? v.istamp : v.zstamp;
@@ -416,6 +435,7 @@ int32_t d3d_ff_export_members(const d3d_ff* ff, int32_t e, int32_t which, int32_
 }
 
 int32_t d3d_ff_export_zone_keys(const d3d_ff* ff, int32_t e, int32_t* cells, int32_t* ids, int32_t cap) {
+    std::lock_guard<std::mutex> d3d_lock_(ff->mu);
     const Env& v = ff->env[e];
     std::vector<std::pair<uint64_t, int32_t>> o;
     for (int32_t i = 0; i < (int32_t)v.zlive.size(); ++i)

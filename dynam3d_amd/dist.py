@@ -36,6 +36,8 @@ def init_from_env(backend: Optional[str] = None):
 
 def gather_metrics(sums: Dict[str, float], n_episodes: int, device="cpu") -> Dict[str, float]:
     """One collective: all_gather of [9 metric sums, count] -> global means (every rank gets the result)."""
+    if dist.is_initialized() and dist.get_backend() == "gloo":
+        device = "cpu"                      # gloo gathers host tensors (RCCL / "nccl" takes the device tensor)
     v = torch.tensor([float(sums.get(k, 0.0)) for k in METRIC_KEYS] + [float(n_episodes)], dtype=torch.float32, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
         out = [torch.empty_like(v) for _ in range(dist.get_world_size())]

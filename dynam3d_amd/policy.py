@@ -76,6 +76,15 @@ class SyntheticTokenizer(PromptTokenizer):
                 out.append(100 + zlib.crc32(piece.encode()) % hi)
         return out
 
+    def split_prompt(self, head: str, n_visual: int, tail: str):
+        """Same result as the generic `PromptTokenizer.split_prompt` (asserted in tests/test_policy_cpu.py) without running the regex
+        over hundreds of "<image>" placeholders per prompt and step: every piece of this tokenizer is context free, so
+        ids(head + "<image>" * n + tail) = ids(head) + [image id] * n + ids(tail)[without BOS]."""
+        h = self.encode(head)
+        t = self.encode(tail)[1 if self.add_bos else 0:]
+        full = h + [self.SPECIAL["<image>"] % self.vocab] * n_visual + t
+        return full[:2], full[n_visual + 2:]
+
     def decode(self, ids: Sequence[int]) -> str:
         inv = {v % self.vocab: k for k, v in self.SPECIAL.items()}
         return " ".join(inv.get(int(i), "\n" if int(i) == self.NEWLINE else f"<{int(i)}>") for i in ids)
@@ -187,7 +196,9 @@ class Dynam3D_VLN:
         B = ff.batch_size
         rgb = observations["rgb"].to(self.device)
         depth = observations["depth"].to(self.device, torch.float32)
-        depth24 = self._depth24(depth, V, depth_scale)                                        # (B,V,576) metres
+        depth24 = self._depth24(depth, V, (0.0, 10.0))                                        # (B,V,576) metres.  VLN-POL:341 calls
+        # `self.preprocess_depth(batch_depth_fts)` WITHOUT depth_scale: the 24x24 depth is always scaled by the (0, 10) default;
+        # only the full-resolution depth of the frustum cull takes the caller's depth_scale (VLN-POL:350)
         pixels = preprocess_rgb(rgb)                                                          # shared by both towers
         cuda = self.device.type == "cuda"
         dfull = patch_pos = None

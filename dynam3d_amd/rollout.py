@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--max-steps", type=int, default=50)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--stop-mod", type=int, default=7, help="an episode stops when its argmax token is divisible by this (huge = never: full-length episodes)")
+    ap.add_argument("--per-rank", action="store_true", help="every rank prints its own wall / CPU seconds (host-side load when ranks share a host)")
     a = ap.parse_args()
     rank, local, world = DD.init_from_env()
     torch.cuda.set_device(local)
@@ -71,9 +72,18 @@ def main():
     D.enable_hip_kernels(["all"])
     cfg = PolicyConfig()
     net = Dynam3D_VLN(cfg, synth_policy_weights(cfg, a.seed, device=dev), device=dev, batch_size=a.episodes_per_rank, max_steps=a.max_steps + 1)
-    t0 = time.time()
+    DD.barrier()
+    t0, c0 = time.time(), time.process_time()
     sums, n = run_rollout(net, a.episodes_per_rank, a.max_steps, seed=a.seed + 1000 * rank, stop_token_mod=a.stop_mod)   # seed + rank (VLN-TR:141)
     torch.cuda.synchronize()
+    wall, cpu = time.time() - t0, time.process_time() - c0
+    if a.per_rank:
+        # host-side load of one rank: wall seconds and CPU seconds (user + system of this process, GPU waits included when the
+        # runtime spins) per environment step -- what N ranks on one host have to share
+        steps = float(sums["steps_taken"])
+        print("RANK", json.dumps(dict(rank=rank, world=world, env_steps=steps, wall_s=round(wall, 3), cpu_s=round(cpu, 3),
+                                      wall_ms_per_batch_step=round(wall / max(steps / a.episodes_per_rank, 1) * 1e3, 2),
+                                      cpu_ms_per_batch_step=round(cpu / max(steps / a.episodes_per_rank, 1) * 1e3, 2))), flush=True)
     res = DD.gather_metrics(sums, n, device=dev)                                                # the ONE collective
     if rank == 0:
         dt = time.time() - t0

@@ -247,6 +247,21 @@ class Phi3Decoder:
         self.lm_head_w = t(sd["language_model.lm_head.weight"])
         self._rope_cache = {}
 
+    MAX_DECODE_ROWS = 16          # k_gemm_skinny: M <= 16
+    MAX_DECODE_KEYS = 4096 + 64   # k_decode_attn keeps one score per key in LDS
+    SLIDING_WINDOW = 2047         # Phi-3-mini-4k-instruct config.json: every layer attends to the last 2047 keys only
+
+    def _check_lengths(self, lens, max_new_tokens: int = 0):
+        """Prompts the kernels do not model: longer than Phi-3-mini's sliding attention window (HF masks keys further back than 2047;
+        here attention is full causal, so results would silently differ) or than the rotary table.  The reference's prompts are
+        2 + 576 + Ni + Nz + text ~ 0.8-1.1 k tokens."""
+        longest = max(lens) + max_new_tokens
+        if longest > self.SLIDING_WINDOW:
+            raise ValueError(f"prompt of {max(lens)} tokens (+{max_new_tokens} generated) exceeds Phi-3-mini's sliding window of {self.SLIDING_WINDOW} keys, "
+                             "which this implementation does not model")
+        if longest > self.cfg.max_pos or longest > self.MAX_DECODE_KEYS:
+            raise ValueError(f"sequence of {longest} tokens exceeds max_position_embeddings = {self.cfg.max_pos}")
+
     def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
         return self.embed_w.index_select(0, ids.reshape(-1)).view(*ids.shape, self.cfg.hidden)
 
@@ -291,6 +306,7 @@ class Phi3Decoder:
         fused-QKV buffer after RoPE -- the prompt part of the KV cache, read in place by `generate_packed`."""
         c = self.cfg
         B, Tp = len(lens), x.shape[0]
+        self._check_lengths(lens)
         cu_h = [0]
         for n in lens:
             cu_h.append(cu_h[-1] + n)
@@ -330,6 +346,26 @@ class Phi3Decoder:
         `return_logits` the (steps, B, vocab) float32 logits.  `forced` (steps x B ids) replaces the argmax (teacher forcing)."""
         c = self.cfg
         B = len(lens)
+        if B > self.MAX_DECODE_ROWS:
+            # the weight-streaming decode kernels take at most 16 rows: larger batches are generated in groups of 16 sequences
+            out_tok, out_logits, cu = [], [], [0]
+            for n in lens:
+                cu.append(cu[-1] + n)
+            for i0 in range(0, B, self.MAX_DECODE_ROWS):
+                i1 = min(B, i0 + self.MAX_DECODE_ROWS)
+                T = cu[i1] - cu[i0]
+                xs = torch.zeros(((T + 255) // 256 * 256, x.shape[1]), dtype=x.dtype, device=x.device)
+                xs[:T] = x[cu[i0]:cu[i1]]
+                r = self.generate_packed(xs, lens[i0:i1], max_new_tokens, end_id, None if forced is None else [f[i0:i1] for f in forced], return_logits)
+                out_tok += r[0] if return_logits else r
+                if return_logits:
+                    out_logits.append(r[1])
+            if return_logits:
+                steps = max(l.shape[0] for l in out_logits)          # groups may stop at different steps (end_id): pad with NaN rows
+                pad = [torch.cat([l, torch.full((steps - l.shape[0],) + tuple(l.shape[1:]), float("nan"), device=l.device)], 0) for l in out_logits]
+                return out_tok, torch.cat(pad, 1)
+            return out_tok
+        self._check_lengths(lens, max_new_tokens)
         kv = []
         logits = self.prefill_logits_packed(x, lens, keep_kv=kv)
         cu = self._last_cu

@@ -68,13 +68,17 @@ def encode_set(tokens: T, cls: T, sd: Dict[str, T], name: str) -> T:
     return encoder_post_ln(seq, sd, name)[0, 0:1]
 
 
-def tcnn_mlp(x: T, weights, act: str = "LeakyReLU", out_act: str = "None") -> T:
+def tcnn_mlp(x: T, weights, act: str = "LeakyReLU", out_act: str = "None", store=None) -> T:
     """tinycudann CutlassMLP as used at PRE-FF:221-243: bias-free layers y = act(x W^T), LeakyReLU slope 0.01 (tiny-cuda-nn's
-    `leaky_relu`), differentiable (plain torch ops) -- the float32 restatement the HIP forward / backward are checked against."""
+    `leaky_relu`), differentiable (plain torch ops) -- the float32 restatement the HIP forward / backward are checked against.
+    store=torch.float16: every layer's output is stored in fp16 like tinycudann's (and the kernels'); the cast is differentiable
+    (identity gradient), and the LeakyReLU slope of the backward pass is then decided on the STORED activation, as it is there."""
     h = x
     for i, w in enumerate(weights):
         h = F.linear(h, w)
         a = out_act if i == len(weights) - 1 else act
         if a == "LeakyReLU":
             h = F.leaky_relu(h, 0.01)
+        if store is not None:
+            h = h.to(store).float()
     return h

@@ -30,8 +30,8 @@ class StepOracle:
     def build_inputs(self, rgb: np.ndarray, depth: np.ndarray, instructions: List[str], positions, headings, patch_segm):
         B = rgb.shape[0]
         t0 = time.time()
-        d24 = G.preprocess_depth(G.downsample_depth_nearest(depth), self.depth_scale).reshape(B, 1, -1)     # VLN-POL:336-341 (F9 fixed)
-        px = TR.preprocess_rgb(rgb, self.vit.image)
+        d24 = G.preprocess_depth(G.downsample_depth_nearest(depth), (0.0, 10.0)).reshape(B, 1, -1)         # VLN-POL:336-341 (F9 fixed): the
+        px = TR.preprocess_rgb(rgb, self.vit.image)                                                         # default scale, not depth_scale
         _, grid = TR.clip_vit_forward(px, self.sd, self.vit.layers, self.vit.heads, self.vit.patch, lowp=self.clip_lowp)   # VLN-POL:344
         t1 = time.time()
         dfull = G.preprocess_depth(depth, self.depth_scale)[..., 0]

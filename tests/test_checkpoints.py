@@ -17,9 +17,20 @@ from tests.cpu_ops import CpuOps
 from tests.test_policy_cpu import SMALL
 
 
-def _write(tmp, sd, cfg, unconverted_ff):
+def _new_hf_key(k):
+    """transformers >= 4.52 LlavaForConditionalGeneration layout."""
+    if k == "language_model.lm_head.weight":
+        return "lm_head.weight"
+    if k.startswith("language_model.model."):
+        return "model.language_model." + k[len("language_model.model."):]
+    return "model." + k
+
+
+def _write(tmp, sd, cfg, unconverted_ff, new_hf_layout=False):
     from safetensors.torch import save_file
     llava = {k: v.contiguous() for k, v in sd.items() if k.startswith(("language_model.", "vision_tower.", "multi_modal_projector."))}
+    if new_hf_layout:
+        llava = {_new_hf_key(k): v for k, v in llava.items()}
     names = sorted(llava)
     half = len(names) // 2
     d = os.path.join(tmp, "llava-phi-3-mini-hf")
@@ -42,6 +53,21 @@ def _write(tmp, sd, cfg, unconverted_ff):
     tr = os.path.join(tmp, "ckpt.iter100.pth")
     torch.save({"state_dict": {"net." + k: sd[k] for k in mlp_names} | {"net.some_other_head.weight": torch.zeros(2)}, "iteration": 100}, tr)
     return d, clip, ffp, tr
+
+
+def test_new_hf_llava_layout_and_prefix_only_ignore_list(tmp_path):
+    """A llava checkpoint saved by transformers >= 4.52 (`model.language_model.layers.*`, top-level `lm_head.weight`) loads into the
+    4.46 names of the spec; feature-field keys are ignored by PREFIX only (a key that merely contains `clip_` / `nerf_` is kept)."""
+    cfg = SMALL
+    sd = synth_policy_weights(cfg, seed=0)
+    d, clip, ffp, tr = _write(str(tmp_path), sd, cfg, False, new_hf_layout=True)
+    got = CK.load_reference_weights(d, clip, ffp, tr, cfg=cfg)
+    for n, _ in phi3_param_spec(cfg.llm) + llava_vision_param_spec(cfg.vit):
+        assert torch.equal(got[n], sd[n]), n
+    assert CK.canonical_llava_key("lm_head.weight") == "language_model.lm_head.weight"
+    p = str(tmp_path / "ff2.pth")
+    torch.save({"patch_clip_gate.weight": torch.ones(2), "nerf_encoder.params": torch.zeros(3), "clip_text.weight": torch.zeros(1)}, p)
+    assert set(CK.load_dynam3d_pth(p)) == {"patch_clip_gate.weight"}
 
 
 @pytest.mark.parametrize("unconverted_ff", [False, True])

@@ -72,10 +72,13 @@ def test_tcnn_network_shim():
     cfg = {"otype": "CutlassMLP", "activation": "LeakyReLU", "output_activation": "LeakyReLU", "n_neurons": 768, "n_hidden_layers": 2}
     net = Network(768, 769, cfg, ws)
     x = torch.randn(1152, 768)
-    y = net(x.cuda()).float().cpu()
+    with torch.no_grad():
+        y = net(x.cuda()).float().cpu()
     ref = RO.tcnn_mlp(x, ws, "LeakyReLU", "LeakyReLU").float()
     assert y.shape == (1152, 769)
     assert float((y - ref).norm() / ref.norm()) < 2e-3
-    flat = torch.cat([w.reshape(-1) for w in ws])
-    y2 = Network.from_flat_params(768, 769, cfg, flat)(x.cuda()).float().cpu()
+    flat = net.flat_from_layers(ws)                       # tinycudann's flat `params` layout: last layer's rows padded 769 -> 784
+    assert flat.numel() == 768 * 768 * 2 + 784 * 768
+    with torch.no_grad():
+        y2 = Network.from_flat_params(768, 769, cfg, flat)(x.cuda()).float().cpu()
     assert torch.equal(y, y2)

@@ -96,3 +96,14 @@ def test_policy_forward_text_matches_oracle_generation():
         assert [h[-1] for h in net.feature_fields.history_actions] == [h[-1] for h in orc.history]
         assert net.convert_text_to_action(got) == net.convert_text_to_action(ref)
 
+
+
+def test_synthetic_tokenizer_fast_split_equals_reference_arithmetic():
+    """`SyntheticTokenizer.split_prompt` (no regex over the placeholders) == the generic `ids[:2]` / `ids[n+2:]` of the full prompt
+    (VLN-POL:436-438, 456), with and without BOS, head shorter / longer than two tokens."""
+    import itertools
+    from dynam3d_amd.adapters import PromptTokenizer
+    for bos in (True, False):
+        t = SyntheticTokenizer(32064, add_bos=bos)
+        for head, n, tail in itertools.product(["<|user|>\n", "", "<|user|>\n a b c d"], [0, 1, 2, 3, 700], ["\nInstruction:\nwalk to x\n<|end|>\n", ""]):
+            assert t.split_prompt(head, n, tail) == PromptTokenizer.split_prompt(t, head, n, tail), (bos, head, n, tail)

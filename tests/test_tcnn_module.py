@@ -56,18 +56,18 @@ def test_tcnn_forward_backward_on_hip_matches_autograd_restatement(out_act, n_ou
     # restatement: float32 autograd on the fp16-rounded weights / inputs (what the kernels consume)
     xr = x.half().float().requires_grad_(True)
     wr = [w.half().float().requires_grad_(True) for w in ws]
-    yr = NN.tcnn_mlp(xr, wr, "LeakyReLU", out_act)
+    yr = NN.tcnn_mlp(xr, wr, "LeakyReLU", out_act, store=torch.float16)
     yr.backward(dy.half().float())
     xg = x.cuda().requires_grad_(True)
     y = net(xg)
     assert y.dtype == torch.float16 and tuple(y.shape) == (rows, n_out)
     y.backward(dy.cuda().half())
-    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
-    assert rel(y.float().cpu(), yr.detach()) < 2e-3
-    assert rel(xg.grad.float().cpu(), xr.grad) < 1e-2                                 # fp16 gradients through two more fp16 layers
+    rel = lambda a, b: float((a.detach().double() - b.detach().double()).norm() / b.detach().double().norm())
     gl = net.layers_from_flat(net.params.grad.detach().cpu())
-    for l, (g, w) in enumerate(zip(gl, wr)):
-        assert rel(g, w.grad) < 1e-2, (l, rel(g, w.grad))
+    errs = dict(y=rel(y.float().cpu(), yr), dx=rel(xg.grad.float().cpu(), xr.grad), **{f"dW{l}": rel(g, w.grad) for l, (g, w) in enumerate(zip(gl, wr))})
+    print("tcnn", out_act, n_out, rows, {k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs["y"] < 1e-3                                                            # same fp16 stores, fp32 accumulation
+    assert all(v < 5e-3 for k, v in errs.items() if k != "y"), errs                    # gradients are fp16 GEMM outputs (tinycudann's too)
     # padding rows of the flat gradient stay zero; the inference path (one C call) returns the same forward
     if n_out == 769:
         assert float(net.params.grad[768 * 768 * 2 + 769 * 768:].abs().sum()) == 0.0
@@ -79,5 +79,5 @@ def test_tcnn_forward_backward_on_hip_matches_autograd_restatement(out_act, n_ou
     with torch.no_grad():
         y2 = net(x.cuda())
     ws2 = [w.detach().float().cpu() for w in net.layers_from_flat(net.params)]
-    assert rel(y2.float().cpu(), NN.tcnn_mlp(x.half().float(), [w.half().float() for w in ws2], "LeakyReLU", out_act)) < 2e-3
+    assert rel(y2.float().cpu(), NN.tcnn_mlp(x.half().float(), [w.half().float() for w in ws2], "LeakyReLU", out_act, store=torch.float16)) < 1e-3
     assert not torch.equal(y2, y.detach())
