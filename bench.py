@@ -211,13 +211,15 @@ def main():
         achieved = gu_flops / (ms_gu * 1e-3) / 1e12 if n_gu else float("nan")
         st = net.feature_fields.state
         traffic, traffic_note = None, None
-        pj = os.path.join(ROOT, "profiles", "r01_pmc_gate_up.json")
+        pj = os.path.join(ROOT, "profiles", "r02_pmc_gate_up.json")
         if os.path.isfile(pj) and dict(D.BACKEND)["linear"] == "hip":
-            # HBM bytes per launch of this kernel from the rocprofv3 PMC passes committed under profiles/ (same kernel, M=7168):
-            # 2*FETCH_SIZE + WRITE_SIZE (FETCH_SIZE counts 128-B requests at 64 B on gfx950, MI355X_MICROARCH.md); scaled by rows.
+            # Fabric-side bytes per launch of this kernel: counters cannot be read inside an un-profiled run, so this is the figure of THIS
+            # ROUND's rocprofv3 --pmc passes over the same kernel (profiles/r02_pmc_gate_up.json: 2 * FETCH_SIZE + WRITE_SIZE, separate
+            # passes; FETCH_SIZE counts 128-B requests at 64 B on gfx950, MI355X_MICROARCH.md), scaled by the rows of this run.
             pm = json.load(open(pj))
-            traffic = int(pm["hbm_bytes_per_launch"] * rows_gemm / float(pm.get("rows", 7168)))
-            traffic_note = "from profiles/r01_pmc_gate_up.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), scaled by launched rows"
+            traffic = int(pm["hbm_bytes_per_launch"] * rows_gemm / float(pm["rows"]))
+            traffic_note = ("from_profile: profiles/r02_pmc_gate_up.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this round's kernel at M = %d), "
+                            "scaled by launched rows; includes Infinity-Cache hits (algorithmic bytes %d)" % (pm["rows"], int(pm["algorithmic_bytes"] * rows_gemm / float(pm["rows"]))))
         out = {
             "metric": "nav steps/sec (RGB-D obs->action logits) at batch=8", "value": round(B * a.steps * a.gpus / dt, 3), "unit": "env-steps/s",
             "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,

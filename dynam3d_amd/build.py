@@ -22,6 +22,7 @@ HIP_SOURCES = [
     ("dense_kernels.hip", ["-ffp-contract=fast"]),
     ("tower_kernels.hip", ["-ffp-contract=off"]),
     ("train_kernels.hip", ["-ffp-contract=off"]),
+    ("f32_kernels.hip", ["-ffp-contract=off"]),
     ("gemm_kernels.hip", ["-ffp-contract=fast"]),
     ("attn_kernels.hip", ["-ffp-contract=fast"]),
     ("render_kernels.hip", ["-ffp-contract=off"]),

@@ -395,7 +395,11 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
         kb = __builtin_amdgcn_readfirstlane(slice * nk / splits);
         ke = __builtin_amdgcn_readfirstlane((slice + 1) * nk / splits);
     }
-    constexpr int GM = 4;
+    // Tile order inside an XCD: GM consecutive M tiles share consecutive N tiles, so the 32 tiles one XCD runs side by side form a
+    // GM x 32/GM block and pull GM A panels + 32/GM W panels per K step through that XCD's L2.  GM = 4 (4 + 8 = 12 panels for 32
+    // tiles) is the production order; the unsplit launch can override it (`splits` carries GM there: D3D_GEMM_GM, an experiment knob
+    // for the cross-XCD duplication measurement in DESIGN.md section 4: GM = 1 is 1 + 32 = 33 panels, 2.75 x the fabric reads).
+    const int GM = SPLIT ? 4 : splits;
     const int group = wg / (GM * tiles_n);
     const int gm0 = group * GM;
     const int gsz = min(GM, tiles_m - gm0);
@@ -556,6 +560,15 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     }
 }
 
+inline int tile_group_m() {
+    static const int gm = [] {
+        const char* e = getenv("D3D_GEMM_GM");
+        const int v = e ? atoi(e) : 4;
+        return v >= 1 && v <= 64 ? v : 4;
+    }();
+    return gm;
+}
+
 template <bool BF16, int EPI, bool KFULL, int DMAV = 0>
 int32_t launch256(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
                   int64_t ldw, int64_t ldc, hipStream_t s) {
@@ -568,7 +581,7 @@ int32_t launch256(const void* A, const void* W, void* C, const void* bias, const
     });
     D3D_HIP(attr_err);
     hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL, false, DMAV>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W,
-                       (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, 1, (float*)nullptr);
+                       (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, tile_group_m(), (float*)nullptr);
     D3D_LAUNCH_CHECK();
 }
 

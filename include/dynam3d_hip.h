@@ -239,6 +239,23 @@ int32_t d3d_gemm_reserve_workspace(void* stream);
 int32_t d3d_mlp768_forward(const void* x_d, int64_t n_rows, int32_t n_in, const void* const* weights, int32_t n_hidden,
                            int32_t n_neurons, int32_t n_out_padded, int32_t act, int32_t out_act, void* scratch_a_d,
                            void* scratch_b_d, void* y_d, void* stream);
+/* ---- float32 dense kernels of the 3D-token builder (a7, a9, a11, a14: VLN-FF:134-161, VLN-POL:83-111) ----------------------------
+ * The set encoders, the merge discriminator and the prefix MLPs are float32 modules whose decisions are pinned bit for bit by golden
+ * trajectories: they run in float32 on v_mfma_f32_16x16x4_f32 (exact f32 multiply-add chain).
+ * C[M,N] = epilogue(A[M,K] W[N,K]^T): epilogue 0 none, 1 +bias, 2 +bias GELU(erf), 3 +bias +residual (residual (M,N), row stride ldc).
+ * K % 16 == 0 (zero-pad operands), N % 4 == 0, strides % 4 == 0. */
+int32_t d3d_gemm_nt_f32(const float* A_d, const float* W_d, float* C_d, const float* bias_d, const float* residual_d, int32_t M, int32_t N,
+                        int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t epilogue, void* stream);
+/* y = [gelu](x W^T + b) for 1 <= K <= 8 (geometry inputs of the position-embedding MLPs; W (N,K) contiguous) */
+int32_t d3d_linear_smallk_f32(const float* x_d, const float* W_d, const float* bias_d, float* y_d, int32_t M, int32_t N, int32_t K, int64_t ldx,
+                              int64_t ldy, int32_t gelu, void* stream);
+/* y = x W^T + b for 1 <= N <= 8 (the merge discriminator's two logits, VLN-FF:157-161; W (N,K) contiguous, K % 4 == 0) */
+int32_t d3d_linear_smalln_f32(const float* x_d, const float* W_d, const float* bias_d, float* y_d, int32_t M, int32_t N, int32_t K, int64_t ldx,
+                              int64_t ldy, void* stream);
+/* y = [gelu](LayerNorm(x [+ residual])) over rows of D <= 3072 floats: post-LN transformer glue and Linear-LN-GELU in one pass */
+int32_t d3d_layer_norm_f32(const float* x_d, const float* residual_d /* optional */, const float* w_d, const float* b_d, float* y_d, int32_t rows,
+                           int32_t D, int64_t ldx, int64_t ldr, int64_t ldy, float eps, int32_t gelu, void* stream);
+
 /* ---- backward pass of the tcnn CutlassMLP replacement (the Pretrain path trains these networks, PRE-FF:221-243) ----
  * All three GEMMs of a layer are d3d_gemm_nt launches on 16-bit operands:
  *   forward        h_l  = act(h_{l-1} W_l^T)                         epilogue 0 / 7
