@@ -23,35 +23,37 @@ using float4v = __attribute__((ext_vector_type(4))) float;
 
 enum EpiF32 : int { F_NONE = 0, F_BIAS = 1, F_BIAS_GELU = 2, F_BIAS_RES = 3 };
 
-constexpr int FBM = 128, FBN = 128, FBK = 16, FPITCH = 24;   // LDS row pitch 24 floats (96 B): ds_read_b128 of lane (row i, k-group g) hits
-                                                             // 16-byte slot (6 i + g) % 16 -- conflict-free for every 16-lane service group
+constexpr int FBK = 16, FPITCH = 24;   // LDS row pitch 24 floats (96 B): ds_read_b128 of lane (row i, k-group g) hits 16-byte slot
+                                       // (6 i + g) % 16 -- conflict-free for every 16-lane service group
+// Tile = (32 WT) x (32 WT) outputs per 256-thread workgroup, every wave (16 WT) x (16 WT) = WT x WT MFMA tiles.  WT = 4: 128 x 128, 64
+// MFMAs per wave and K step -- the throughput shape.  WT = 2: 64 x 64, 16 MFMAs per step -- four times as many workgroups and a
+// quarter of the serial MFMA chain per K step, for the small-M launches (the CLS-only second encoder layer, zone sets, merge
+// discriminator: M = 100-500 rows) whose time is K/16 dependent steps, not FLOPs.
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-// One 128 x 16 operand tile: thread t loads rows (t >> 2) and (t >> 2) + 64, floats [4 (t & 3), +4).  Rows beyond `rows_valid` re-read the
-// last valid row (their outputs are never stored).
-struct Stage {
-    float4 v[2];
-};
-
-__device__ __forceinline__ void load_tile(Stage& s, const float* __restrict__ base, int64_t ld, int row0, int rows_valid, int k0, int tid) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        int r = row0 + (tid >> 2) + h * 64;
-        r = r < rows_valid ? r : rows_valid - 1;
-        s.v[h] = *reinterpret_cast<const float4*>(base + (int64_t)r * ld + k0 + (tid & 3) * 4);
-    }
+// One 128 x 16 operand tile: thread t moves rows (t >> 2) and (t >> 2) + 64, floats [4 (t & 3), +4).  Rows beyond the operand's last
+// row re-read that row (their outputs are never stored).
+//
+// The prefetch loads are INLINE ASM.  hipcc sinks ordinary loads to their first use: written as C++ (one- or two-step prefetch distance,
+// named registers, alternating register sets -- all tried) the loads of the next tile were always issued behind the 64 MFMAs, right in
+// front of the ds_write that consumes them, and their latency was exposed on every K step (a struct / array of staged values was even
+// demoted to scratch memory).  An asm load is invisible to that pass; it is waited for by hand (vmcnt(0) tied to the four registers).
+__device__ __forceinline__ const float* row_ptr(const float* __restrict__ base, int64_t ld, int row, int rows_valid) {
+    row = row < rows_valid ? row : rows_valid - 1;
+    return base + (int64_t)row * ld;
 }
 
-__device__ __forceinline__ void store_tile(const Stage& s, float* __restrict__ lds, int tid) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) *reinterpret_cast<float4*>(lds + ((tid >> 2) + h * 64) * FPITCH + (tid & 3) * 4) = s.v[h];
+__device__ __forceinline__ void gload4(float4v& d, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
 }
 
-template <int EPI>
+template <int EPI, int WT>
 __global__ void __launch_bounds__(256, 2)
 k_gemm_f32(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ C, const float* __restrict__ bias,
            const float* __restrict__ residual, int M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int tiles_m, int tiles_n) {
+    constexpr int FBM = 32 * WT, FBN = 32 * WT, WAVE_T = 16 * WT;
+    constexpr int NLD = FBM / 64;                                                 // float4 loads per thread and operand tile
     __shared__ __attribute__((aligned(16))) float smem[2][2][FBM * FPITCH];      // [buffer][A | W]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // consecutive workgroups walk the N tiles of one group of 4 M tiles: the W panels stay hot in L2
@@ -66,30 +68,53 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ W, float* __re
     const int wr = wave >> 1, wc = wave & 1;
     const int fi = lane & 15, fg = lane >> 4;
 
-    float4v acc[4][4];        // [i: M tile][j: N tile]; D = W_frag x A_frag -> lane holds C[m = i-tile row fi][n = j-tile rows 4 fg .. +3]
+    float4v acc[WT][WT];      // [i: M tile][j: N tile]; D = W_frag x A_frag -> lane holds C[m = i-tile row fi][n = j-tile rows 4 fg .. +3]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < WT; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / FBK;
-    Stage sa, sw;
-    load_tile(sa, A, lda, row0, M, 0, tid);
-    load_tile(sw, W, ldw, col0, N, 0, tid);
-    store_tile(sa, smem[0][0], tid);
-    store_tile(sw, smem[0][1], tid);
+    const int lr = tid >> 2, lc = (tid & 3) * 4;             // this thread's row (and row + 64 at WT = 4) / first float of the staged tiles
+    const int lds_off = lr * FPITCH + lc;
+    const float* pa0 = row_ptr(A, lda, row0 + lr, M) + lc;
+    const float* pa1 = row_ptr(A, lda, row0 + lr + 64, M) + lc;
+    const float* pw0 = row_ptr(W, ldw, col0 + lr, N) + lc;
+    const float* pw1 = row_ptr(W, ldw, col0 + lr + 64, N) + lc;
+    float4v a0, a1, w0, w1;
+    auto issue = [&](int k) {
+        gload4(a0, pa0 + k);
+        gload4(w0, pw0 + k);
+        if constexpr (NLD == 2) {
+            gload4(a1, pa1 + k);
+            gload4(w1, pw1 + k);
+        }
+    };
+    auto land = [&](int buf) {
+        if constexpr (NLD == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(w0), "+v"(w1)::"memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(w0)::"memory");
+        }
+        *reinterpret_cast<float4v*>(smem[buf][0] + lds_off) = a0;
+        *reinterpret_cast<float4v*>(smem[buf][1] + lds_off) = w0;
+        if constexpr (NLD == 2) {
+            *reinterpret_cast<float4v*>(smem[buf][0] + lds_off + 64 * FPITCH) = a1;
+            *reinterpret_cast<float4v*>(smem[buf][1] + lds_off + 64 * FPITCH) = w1;
+        }
+    };
+    issue(0);
+    land(0);
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nk) {                                   // next tile's global loads fly under this tile's 64 MFMAs
-            load_tile(sa, A, lda, row0, M, (t + 1) * FBK, tid);
-            load_tile(sw, W, ldw, col0, N, (t + 1) * FBK, tid);
-        }
-        const float* la = smem[cur][0] + (wr * 64 + fi) * FPITCH + fg * 4;
-        const float* lw = smem[cur][1] + (wc * 64 + fi) * FPITCH + fg * 4;
-        float4 af[4], wf[4];
+        issue((t + 1 < nk ? t + 1 : t) * FBK);               // next tile in flight under this step's MFMAs (the last step re-loads its own: never used)
+        __builtin_amdgcn_sched_barrier(0);
+        const float* la = smem[cur][0] + (wr * WAVE_T + fi) * FPITCH + fg * 4;
+        const float* lw = smem[cur][1] + (wc * WAVE_T + fi) * FPITCH + fg * 4;
+        float4 af[WT], wf[WT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < WT; ++i) {
             af[i] = *reinterpret_cast<const float4*>(la + i * 16 * FPITCH);
             wf[i] = *reinterpret_cast<const float4*>(lw + i * 16 * FPITCH);
         }
@@ -98,26 +123,24 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ W, float* __re
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < WT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < WT; ++j) {
                     const float a = c == 0 ? af[i].x : c == 1 ? af[i].y : c == 2 ? af[i].z : af[i].w;
                     const float w = c == 0 ? wf[j].x : c == 1 ? wf[j].y : c == 2 ? wf[j].z : wf[j].w;
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, a, acc[i][j], 0, 0, 0);
                 }
-        if (t + 1 < nk) {
-            store_tile(sa, smem[cur ^ 1][0], tid);
-            store_tile(sw, smem[cur ^ 1][1], tid);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        land(cur ^ 1);
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = row0 + wr * 64 + i * 16 + fi;
+    for (int i = 0; i < WT; ++i) {
+        const int m = row0 + wr * WAVE_T + i * 16 + fi;
         if (m >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = col0 + wc * 64 + j * 16 + fg * 4;
+        for (int j = 0; j < WT; ++j) {
+            const int n = col0 + wc * WAVE_T + j * 16 + fg * 4;
             if (n >= N) continue;
             float4v v = acc[i][j];
             if constexpr (EPI != F_NONE) {
@@ -261,12 +284,20 @@ int32_t d3d_gemm_nt_f32(const float* A, const float* W, float* C, const float* b
         d3d_set_error_("d3d_gemm_nt_f32: epilogue needs bias (1, 2, 3) / residual (3)");
         return D3D_EINVAL;
     }
-    const int tm = (M + FBM - 1) / FBM, tn = (N + FBN - 1) / FBN;
+    // 128 x 128 tiles when they cover at least half the CUs, 64 x 64 tiles otherwise (see k_gemm_f32)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool big = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * 2 >= cus;
+    const int T = big ? 128 : 64;
+    const int tm = (M + T - 1) / T, tn = (N + T - 1) / T;
     dim3 grid(tm * tn), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define D3D_F32_CASE(E)                                                                                                         \
-    case E:                                                                                                                     \
-        hipLaunchKernelGGL((k_gemm_f32<E>), grid, block, 0, s, A, W, C, bias, residual, M, N, K, lda, ldw, ldc, tm, tn);           \
+#define D3D_F32_CASE(E)                                                                                                             \
+    case E:                                                                                                                         \
+        if (big)                                                                                                                    \
+            hipLaunchKernelGGL((k_gemm_f32<E, 4>), grid, block, 0, s, A, W, C, bias, residual, M, N, K, lda, ldw, ldc, tm, tn);      \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((k_gemm_f32<E, 2>), grid, block, 0, s, A, W, C, bias, residual, M, N, K, lda, ldw, ldc, tm, tn);      \
         break;
     switch (epilogue) {
         D3D_F32_CASE(F_NONE)

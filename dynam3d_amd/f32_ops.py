@@ -1,0 +1,102 @@
+"""ctypes wrappers of the float32 dense kernels of the 3D-token builder (csrc/f32_kernels.hip): fp32 MFMA GEMM with fused
+bias / GELU / residual, the tiny-K and tiny-N linears, and LayerNorm with fused residual add / GELU.  `Mlp` and `linear`
+pick the kernel by shape; weights whose K is not a multiple of 16 are zero-padded once (`prep_weight`)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import f32, i32, i64, vp
+
+_lib.register("d3d_gemm_nt_f32", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp])
+_lib.register("d3d_linear_smallk_f32", [vp, vp, vp, vp, i32, i32, i32, i64, i64, i32, vp])
+_lib.register("d3d_linear_smalln_f32", [vp, vp, vp, vp, i32, i32, i32, i64, i64, vp])
+_lib.register("d3d_layer_norm_f32", [vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, f32, i32, vp])
+
+EPI = dict(none=0, bias=1, bias_gelu=2, bias_res=3)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class F32Ops:
+    def __init__(self):
+        self.lib = _lib.load()
+        self._padded: Dict[int, torch.Tensor] = {}
+
+    def prep_weight(self, w: torch.Tensor) -> torch.Tensor:
+        """(N, K) float32 contiguous; K zero-padded to a multiple of 16 for the MFMA kernel (cached per tensor)."""
+        N, K = w.shape
+        if K % 16 == 0 or K <= 8 or N <= 8:
+            return w
+        key = w.data_ptr()
+        if key not in self._padded:
+            wp = torch.zeros((N, (K + 15) // 16 * 16), dtype=torch.float32, device=w.device)
+            wp[:, :K] = w
+            self._padded[key] = wp
+        return self._padded[key]
+
+    def linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, act: Optional[str] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """y = act(x w^T + b) [+ residual]; x (M, K) float32 (row stride % 4 == 0), w (N, K)."""
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        if M == 0:
+            return y
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        if K <= 8:
+            assert residual is None
+            _lib.check(self.lib.d3d_linear_smallk_f32(_p(x), _p(w), _p(b), _p(y), M, N, K, x.stride(0), N, 1 if act == "gelu" else 0, _stream()))
+            return y
+        if N <= 8:
+            assert act is None and residual is None
+            if x.stride(0) % 4:
+                x = x.contiguous()
+            _lib.check(self.lib.d3d_linear_smalln_f32(_p(x), _p(w), _p(b), _p(y), M, N, K, x.stride(0), N, _stream()))
+            return y
+        wp = self.prep_weight(w)
+        Kp = wp.shape[1]
+        if Kp != K or x.stride(0) % 4:                      # activations with an odd K (the 1539-wide merge input): zero-padded copy
+            xp = torch.zeros((M, Kp), dtype=torch.float32, device=x.device)
+            xp[:, :K] = x
+            x = xp
+        if residual is not None:
+            residual = residual.contiguous()
+            epi = "bias_res"
+        else:
+            epi = "bias_gelu" if act == "gelu" else "bias"
+        _lib.check(self.lib.d3d_gemm_nt_f32(_p(x), _p(wp), _p(y), _p(b), _p(residual), M, N, Kp, x.stride(0), Kp, N, EPI[epi], _stream()))
+        return y
+
+    def layer_norm(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None, gelu: bool = False) -> torch.Tensor:
+        """[gelu](LayerNorm(x [+ residual])), rows of D <= 3072."""
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1 or x2.stride(0) % 4:
+            x2 = x2.contiguous()
+        rows, D = x2.shape
+        y = torch.empty((rows, D), dtype=torch.float32, device=x.device)
+        if rows == 0:
+            return y.view(x.shape)
+        r2 = None
+        if residual is not None:
+            r2 = residual.reshape(-1, D)
+            if r2.stride(1) != 1 or r2.stride(0) % 4:
+                r2 = r2.contiguous()
+        _lib.check(self.lib.d3d_layer_norm_f32(_p(x2), _p(r2), _p(w), _p(b), _p(y), rows, D, x2.stride(0), 0 if r2 is None else r2.stride(0), D, eps,
+                                               1 if gelu else 0, _stream()))
+        return y.view(x.shape)
+
+    def mlp(self, x: torch.Tensor, w: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
+        """nn.Sequential(Linear, LayerNorm, GELU, Linear) (VLN-FF:139-161, VLN-POL:83-111): 3 launches."""
+        h = self.linear(x, w[name + ".0.weight"], w[name + ".0.bias"])
+        h = self.layer_norm(h, w[name + ".1.weight"], w[name + ".1.bias"], 1e-5, gelu=True)
+        return self.linear(h, w[name + ".3.weight"], w[name + ".3.bias"])

@@ -20,10 +20,19 @@ class FFDense:
         self.n_head = n_head
         self.width = self.w["aggregate_patch_to_instance_embedding"].shape[-1]
         self._hd = None
+        self._f32ops = None
+
+    def _f32(self):
+        if self._f32ops is None:
+            from .f32_ops import F32Ops
+            self._f32ops = F32Ops()
+        return self._f32ops
 
     # nn.Sequential(Linear, LayerNorm, GELU, Linear)
     def mlp(self, x: torch.Tensor, name: str) -> torch.Tensor:
         w = self.w
+        if self.device.type == "cuda":                     # fp32 MFMA GEMM + fused LN/GELU (csrc/f32_kernels.hip): 3 launches
+            return self._f32().mlp(x.reshape(-1, x.shape[-1]), w, name).view(*x.shape[:-1], -1)
         h = F.linear(x, w[name + ".0.weight"], w[name + ".0.bias"])
         h = F.layer_norm(h, (h.shape[-1],), w[name + ".1.weight"], w[name + ".1.bias"], 1e-5)
         return F.linear(F.gelu(h), w[name + ".3.weight"], w[name + ".3.bias"])
@@ -80,18 +89,20 @@ class FFDense:
         set_off = torch.from_numpy(poff.astype(np.int32)).to(dev)
         cls_t = torch.from_numpy(cls_rows).to(dev)
         max_len = int(lens.max()) + 1
-        for i in range(2):
+        f = self._f32()
+        for i in range(2):                                                # post-LN nn.TransformerEncoderLayer: 7 launches per layer
             p = f"{enc}.layers.{i}"
             last = i == 1
-            qkv = F.linear(x, w[p + ".self_attn.in_proj_weight"], w[p + ".self_attn.in_proj_bias"])
+            qkv = f.linear(x, w[p + ".self_attn.in_proj_weight"], w[p + ".self_attn.in_proj_bias"])
             a = self._hd.set_attention(qkv, set_off, G, H, max_len, q_rows=1 if last else 0)
             if last:                                                      # only the CLS rows feed the output
                 a, x = a.index_select(0, cls_t), x.index_select(0, cls_t)
-            a = F.linear(a, w[p + ".self_attn.out_proj.weight"], w[p + ".self_attn.out_proj.bias"])
-            x = F.layer_norm(x + a, (D,), w[p + ".norm1.weight"], w[p + ".norm1.bias"], 1e-5)
-            h = F.linear(F.gelu(F.linear(x, w[p + ".linear1.weight"], w[p + ".linear1.bias"])), w[p + ".linear2.weight"], w[p + ".linear2.bias"])
-            x = F.layer_norm(x + h, (D,), w[p + ".norm2.weight"], w[p + ".norm2.bias"], 1e-5)
-        return F.layer_norm(x, (D,), w[enc + ".norm.weight"], w[enc + ".norm.bias"], 1e-12)
+            a = f.linear(a, w[p + ".self_attn.out_proj.weight"], w[p + ".self_attn.out_proj.bias"])
+            x = f.layer_norm(a, w[p + ".norm1.weight"], w[p + ".norm1.bias"], 1e-5, residual=x)              # LN(x + attn)
+            h = f.linear(x, w[p + ".linear1.weight"], w[p + ".linear1.bias"], act="gelu")
+            h = f.linear(h, w[p + ".linear2.weight"], w[p + ".linear2.bias"])
+            x = f.layer_norm(h, w[p + ".norm2.weight"], w[p + ".norm2.bias"], 1e-5, residual=x)              # LN(x + ffn)
+        return f.layer_norm(x, w[enc + ".norm.weight"], w[enc + ".norm.bias"], 1e-12)
 
     def _encode_sets_padded(self, emb: torch.Tensor, lens: Sequence[int], which: str) -> torch.Tensor:
         """Host-logic path used by the CPU tests (tests/cpu_ops.py): same arithmetic on padded buckets."""

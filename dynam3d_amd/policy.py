@@ -159,8 +159,16 @@ class Dynam3D_VLN:
         reference evaluates these layers under autocast."""
         import torch.nn.functional as F
         w = self.mlp_w
-        h = F.linear(x, w[name + ".0.weight"], w[name + ".0.bias"])
-        h = F.gelu(F.layer_norm(h, (h.shape[-1],), w[name + ".1.weight"], w[name + ".1.bias"], 1e-5))
+        if x.is_cuda:                                    # float32 kernels of the token builder (csrc/f32_kernels.hip): Linear, then LN + GELU fused
+            f = self.feature_fields.dense._f32()
+            x2 = x.reshape(-1, x.shape[-1])
+            h = f.layer_norm(f.linear(x2, w[name + ".0.weight"], w[name + ".0.bias"]), w[name + ".1.weight"], w[name + ".1.bias"], 1e-5, gelu=True)
+            h = h.view(*x.shape[:-1], -1)
+            if not (lowp and self.cfg.llava_dtype != torch.float32):
+                return f.linear(h.reshape(-1, h.shape[-1]), w[name + ".3.weight"], w[name + ".3.bias"]).view(*x.shape[:-1], -1)
+        else:
+            h = F.linear(x, w[name + ".0.weight"], w[name + ".0.bias"])
+            h = F.gelu(F.layer_norm(h, (h.shape[-1],), w[name + ".1.weight"], w[name + ".1.bias"], 1e-5))
         if lowp and x.is_cuda and self.cfg.llava_dtype != torch.float32:
             dt = self.cfg.llava_dtype
             key = name + ".3.weight." + str(dt)

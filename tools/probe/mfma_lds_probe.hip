@@ -10,6 +10,7 @@
 //   mode 0: waves 0-3: MFMA steps, waves 4-7 idle                      mode 1: waves 4-7: LDS steps, waves 0-3 idle
 //   mode 2: waves 0-3 MFMA steps  ||  waves 4-7 LDS steps (partners)   mode 3: every wave: 24 reads then 64 MFMAs per step
 //   mode 4: all 8 waves MFMA steps (two waves share each SIMD's matrix pipe)
+//   mode 5: every wave: 64 MFMAs with the 24 reads of the next (half) step interleaved one per ~3 MFMAs
 //
 // build: hipcc --offload-arch=gfx950 -O3 -o mfma_lds_probe mfma_lds_probe.hip ; run: ./mfma_lds_probe
 #include <hip/hip_runtime.h>
@@ -67,6 +68,23 @@ __global__ void __launch_bounds__(512, 2) k_probe(float* out, unsigned long long
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&frag[(i + r) % 24]),
                                                                      *reinterpret_cast<const bf16x8*>(&frag[(i * 5 + r) % 24]), acc[i], 0, 0, 0);
         }
+        if constexpr (MODE == 5) {
+            // software-pipelined half steps: 32 MFMAs on fragment set `cur` (12 registers of 16 B) while the 12 ds_read_b128 of the
+            // NEXT half step land in the other set -- one read issued after every ~3rd MFMA, no burst
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4* cur = frag + (h ? 12 : 0);
+                uint4* nxt = frag + (h ? 0 : 12);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    acc[i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&cur[i % 12]),
+                                                                          *reinterpret_cast<const bf16x8*>(&cur[(i * 5 + 1) % 12]), acc[i & 15], 0, 0, 0);
+                    if (i % 3 == 0 && i / 3 < 12) nxt[i / 3] = *reinterpret_cast<const uint4*>(base + (h * 12 + i / 3) * 512);   // next half step's operands
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    // 1 MFMA ...
+                    if (i % 3 == 0 && i / 3 < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      // ... then 1 DS read
+                }
+            }
+        }
     }
     float s = 0.f;
 #pragma unroll
@@ -111,7 +129,7 @@ int run(const char* name, float* out, unsigned long long* cyc_d, int iters, Res*
             else m_hi = std::max(m_hi, h[b2 * 8 + w]);
         }
     res->ms = best;
-    res->cyc_mfma = (MODE == 0 || MODE == 2) ? (double)m_lo / iters : ((MODE == 3 || MODE == 4) ? (double)std::max(m_lo, m_hi) / iters : 0.0);
+    res->cyc_mfma = (MODE == 0 || MODE == 2) ? (double)m_lo / iters : ((MODE >= 3) ? (double)std::max(m_lo, m_hi) / iters : 0.0);
     res->cyc_lds = (MODE == 1 || MODE == 2) ? (double)m_hi / iters : (MODE == 3 ? (double)std::max(m_lo, m_hi) / iters : 0.0);
     printf("%-36s %8.3f ms   cycles/step: mfma waves %8.1f   lds waves %8.1f   (counter rate %.3f GHz)\n", name, best, res->cyc_mfma, res->cyc_lds,
            (double)std::max(m_lo, m_hi) / (best * 1e-3) / 1e9);
@@ -124,12 +142,13 @@ int main() {
     CHECK(hipMalloc(&out, 256 * 512 * sizeof(float)));
     CHECK(hipMalloc(&cyc, 256 * 8 * sizeof(unsigned long long)));
     const int iters = 4000;
-    Res r0, r1, r2, r3, r4;
+    Res r0, r1, r2, r3, r4, r5;
     if (run<0>("0: MFMA, one wave per SIMD", out, cyc, iters, &r0)) return 1;
     if (run<1>("1: LDS reads, one wave per SIMD", out, cyc, iters, &r1)) return 1;
     if (run<2>("2: MFMA wave || LDS wave per SIMD", out, cyc, iters, &r2)) return 1;
     if (run<3>("3: 2 waves/SIMD, reads then MFMAs", out, cyc, iters, &r3)) return 1;
     if (run<4>("4: MFMA, two waves per SIMD", out, cyc, iters, &r4)) return 1;
+    if (run<5>("5: 2 waves/SIMD, reads INTERLEAVED", out, cyc, iters, &r5)) return 1;
     printf("\nwall time per step (64 MFMAs, 24 KiB of ds_read_b128 per wave), ns -- ratios are clock independent:\n");
     const double n0 = r0.ms * 1e6 / iters, n1 = r1.ms * 1e6 / iters, n2 = r2.ms * 1e6 / iters, n3 = r3.ms * 1e6 / iters, n4 = r4.ms * 1e6 / iters;
     printf("  one MFMA wave per SIMD alone   %7.1f ns = %.2f ns per MFMA\n", n0, n0 / 64);
@@ -139,5 +158,8 @@ int main() {
     printf("  GEMM-like step (mode 3)        %7.1f ns for 2 x (24 reads + 64 MFMAs) per SIMD; matrix-pipe-only time %.1f ns -> pipe busy at most %.0f %%;\n"
            "                                 pipe + LDS-alone times: %.1f ns (additive model) vs max %.1f ns (perfect overlap)\n",
            n3, n4, 100 * n4 / n3, n4 + 2 * n1, std::max(n4, 2 * n1));
+    const double n5 = r5.ms * 1e6 / iters;
+    printf("  interleaved reads (mode 5)     %7.1f ns for 2 x (24 reads + 64 MFMAs) per SIMD, one read behind every 3rd MFMA, fragments double-buffered\n"
+           "                                 by half steps -> pipe busy at most %.0f %% (burst reads, mode 3: %.0f %%)\n", n5, 100 * n4 / n5, 100 * n4 / n3);
     return 0;
 }
