@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <vector>
 #include <unordered_map>
 
 #include "../../include/dynam3d_hip.h"
@@ -380,6 +381,15 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2][A 256x64 | B 256x64]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = K / BK;
+    // DMAV bit 4: timing build (tile codes 301-303, diagnostics only): every wave 0 reports shader-clock cycles (s_memtime) at kernel
+    // start / K-loop start / K-loop end / kernel end and the constant 100 MHz counter at start / end into `ws` (6 x u64 per workgroup).
+    constexpr bool TIMED = (DMAV & 16) != 0;
+    constexpr int DV = DMAV & 15;
+    unsigned long long tk[4] = {0, 0, 0, 0}, tr = 0;
+    if constexpr (TIMED) {
+        tk[0] = __builtin_readcyclecounter();
+        tr = __builtin_amdgcn_s_memrealtime();
+    }
     const int nwg = SPLIT ? dp_tiles : tiles_m * tiles_n;
     int wg = blockIdx.x;
     int kb = 0, ke = nk, slice = 0, tail_idx = -1;
@@ -457,7 +467,72 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     // barrier up front, so it always runs exactly one step behind group 0 (and group 0 one extra at the end).
     // Tile t+1 goes in flight at the start of tile t and must have landed one step before group 0 reads it:
     // group 0 drains its share at the end of its last step of the tile, group 1 (a step late) one step earlier.
-    if constexpr (DMAV == 1) {
+    if constexpr (TIMED) {
+        tk[1] = __builtin_readcyclecounter();
+    }
+    if constexpr (DV >= 2) {
+        // DMAV 2 ("interleaved"): both waves of a SIMD run the SAME software-pipelined stream -- no LOAD phase at all.  A phase is the
+        // 32 MFMAs of one K-half out of fragment set `cs`, with the 12 ds_read_b128 of the NEXT K-half (set cs^1) issued one behind
+        // every ~3rd MFMA, and, in the second phase of a tile, the 8 LDS-DMA pieces of tile t+2 in between as well:
+        //
+        //     P(t,0): MFMA(t, kk=0)  ||  reads (t, kk=1)                           | wait DMA(t+1) + own reads, ONE barrier per tile
+        //     P(t,1): MFMA(t, kk=1)  ||  reads (t+1, kk=0)  ||  DMA(t+2) -> buffer of tile t (every wave is done with it)
+        //
+        // tools/probe/mfma_lds_probe.hip mode 5 is this loop without the DMA and the barrier: the matrix pipe is busy 97 % of the
+        // time, against 80 % when the 24 reads of a tile are issued as one burst (mode 3) -- reads behind MFMAs are nearly free,
+        // bursts are not (profiles/r02_mfma_lds_probe.txt).
+        static_assert(KFULL, "DMAV 2 holds both K-halves in registers");
+        auto PHASE = [&](const int cs, const uint16_t* la, const int kk, const bool rd, const bool dma, const uint16_t* asrc,
+                         const uint16_t* wsrc, const uint32_t dst) {
+            const int ns = cs ^ 1;
+            const uint16_t* lb = la + TM * BK;
+#pragma unroll
+            for (int m = 0; m < 32; ++m) {
+                const int i = m >> 2, j = m & 3;
+                acc[i][j] = mfma16<BF16>(bf[cs][j], af[cs][i], acc[i][j]);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (rd) {
+#pragma unroll
+                    for (int r = 0; r < 12; ++r) {
+                        if ((r * 8) / 3 != m) continue;
+                        if (r < 4) {
+                            const int rb = wn * 64 + r * 16 + fi;
+                            bf[ns][r] = *reinterpret_cast<const uint4*>(lb + rb * BK + (((kk * 4 + fg) ^ (rb & 7)) << 3));
+                        } else {
+                            const int ra = grp * 128 + (r - 4) * 16 + fi;
+                            af[ns][r - 4] = *reinterpret_cast<const uint4*>(la + ra * BK + (((kk * 4 + fg) ^ (ra & 7)) << 3));
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                if (dma && m % 3 == 1 && m / 3 < 8) {
+                    const int p = m / 3;                       // pieces 0-3: A, 4-7: W
+                    if (p < 4) stage_piece_dma(ta.off[p], asrc, dst + (uint32_t)p * 8192u);
+                    else stage_piece_dma(tw.off[p - 4], wsrc, dst + TM * BK * 2 + (uint32_t)(p - 4) * 8192u);
+                }
+            }
+        };
+        auto TILE = [&](const int t, const bool rd, const bool dma) {
+            const uint16_t* la = smem + ((t - kb) & 1) * BUF;
+            const uint16_t* ln = smem + ((t + 1 - kb) & 1) * BUF;
+            PHASE(0, la, 1, true, false, nullptr, nullptr, 0u);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // (DMAV 3 / 4 are timing experiments with WRONG results: 3 re-reads the first K tile every step -- cache-hot operands --,
+            //  4 issues no loads inside the loop at all: what is left is MFMA + ds_read + barrier.  DESIGN.md section 4.)
+            const int ts = DV == 3 ? kb : t + 2;
+            PHASE(1, ln, 0, rd, dma && DV != 4, abase + ts * BK, wbase + ts * BK, lds0 + ((t - kb) & 1) * (BUF * 2) + (uint32_t)wave * 1024u);
+        };
+        if (kb + 1 < ke) {
+            stage_tile_dma<8>(ta, abase + (kb + 1) * BK, lds0 + BUF * 2, wave);
+            stage_tile_dma<8>(tw, wbase + (kb + 1) * BK, lds0 + BUF * 2 + TM * BK * 2, wave);
+        }
+        LOAD(kb, 0, 0);
+        int t = kb;
+        for (; t < ke - 2; ++t) TILE(t, true, true);
+        if (t < ke - 1) TILE(t++, true, false);
+        TILE(t, false, false);
+    } else if constexpr (DV == 1) {
         // DMAV 1: the A pieces of tile t+1 are issued in the LOAD phase, the W pieces between the MFMAs of the COMPUTE phase
         // (tile t+1 for group 0, tile t+2 for group 1, whose COMPUTE(t) runs beside group 0's LOAD(t+1)): the LOAD phase --
         // 8 LDS-DMA issues + 24 ds_read_b128 -- was longer than the partner's 64 MFMAs.
@@ -529,8 +604,14 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
         }
     }
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
+    if (DV < 2 && grp == 0) __builtin_amdgcn_s_barrier();
+    if constexpr (TIMED) {
+        tk[2] = __builtin_readcyclecounter();
+    }
 
+    if constexpr (DV == 5) {
+        if (K != 7) return;                    // timing experiment: no epilogue at all (the stores stay reachable, so the loop is kept)
+    }
     if constexpr (SPLIT) {
         if (tail_idx >= 0) {
             // A K-slice of a tail tile: its fp32 accumulators go to the workspace slot (tile, slice) -- entry e = i*4 + j holds
@@ -558,6 +639,21 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
             for (int j = 0; j < 4; ++j) store4<BF16, EPI>(acc[i][j], acc[i][j], C, bias, residual, m, col0 + wn * 64 + j * 16, fg, ldc);
         }
     }
+    if constexpr (TIMED) {
+        tk[3] = __builtin_readcyclecounter();
+        const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(ws) + (size_t)blockIdx.x * 6;
+            o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3]; o[4] = tr; o[5] = tr1;
+        }
+    }
+}
+
+// K-loop of the 256 x 256 kernels picked by d3d_gemm_nt: the interleaved loop (tile codes 260 / 264) unless D3D_GEMM_LOOP=0 asks for
+// the staggered wave-group loop (257 / 258) -- an A/B knob; both are parity-tested.
+inline bool gemm_loop_interleaved() {
+    static const bool v = [] { const char* e = getenv("D3D_GEMM_LOOP"); return !(e && e[0] == '0'); }();
+    return v;
 }
 
 inline int tile_group_m() {
@@ -580,8 +676,26 @@ int32_t launch256(const void* A, const void* W, void* C, const void* bias, const
         attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, KFULL, false, DMAV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     });
     D3D_HIP(attr_err);
+    float* dbg = nullptr;
+    if constexpr ((DMAV & 16) != 0) D3D_HIP(hipMalloc(&dbg, (size_t)tm * tn * 6 * sizeof(unsigned long long)));
     hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL, false, DMAV>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W,
-                       (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, tile_group_m(), (float*)nullptr);
+                       (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, tile_group_m(), dbg);
+    if constexpr ((DMAV & 16) != 0) {
+        // diagnostics: per-workgroup cycle stamps -> one line on stderr (mean over workgroups)
+        D3D_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h((size_t)tm * tn * 6);
+        D3D_HIP(hipMemcpy(h.data(), dbg, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost));
+        D3D_HIP(hipFree(dbg));
+        double pre = 0, loop = 0, epi = 0, ghz = 0;
+        for (int i = 0; i < tm * tn; ++i) {
+            const unsigned long long* o = &h[(size_t)i * 6];
+            pre += (double)(o[1] - o[0]), loop += (double)(o[2] - o[1]), epi += (double)(o[3] - o[2]);
+            ghz += (double)(o[3] - o[0]) / ((double)(o[5] - o[4]) * 10.0);
+        }
+        const double n = tm * tn;
+        fprintf(stderr, "[d3d gemm timing] variant %d  M %d N %d K %d: workgroups %d, shader clock %.3f GHz, cycles per workgroup: prologue %.0f, K loop %.0f (%.1f per K tile; 128 MFMAs per SIMD = 2061 pipe cycles), epilogue %.0f\n",
+                DMAV & 15, M, N, K, tm * tn, ghz / n, pre / n, loop / n, loop / n / (K / BK), epi / n);
+    }
     D3D_LAUNCH_CHECK();
 }
 
@@ -676,13 +790,13 @@ inline void split_plan(int tiles, int nk, int* dp_tiles, int* splits) {
     *splits = sp < 1 ? 1 : sp;
 }
 
-template <bool BF16, int EPI>
+template <bool BF16, int EPI, int DMAV = 0>
 int32_t launch256_split(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
                         int64_t ldw, int64_t ldc, hipStream_t s) {
     const int tm = (M + TM - 1) / TM, tn = N / TN, tiles = tm * tn;
     int dp_tiles, splits;
     split_plan(tiles, K / BK, &dp_tiles, &splits);
-    if (splits < 2) return launch256<BF16, EPI, true>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s);
+    if (splits < 2) return launch256<BF16, EPI, true, DMAV>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s);
     const int tail = tiles - dp_tiles;
     SplitWorkspace* w = nullptr;
     int32_t rc = split_workspace(s, cu_count(), &w);
@@ -691,10 +805,10 @@ int32_t launch256_split(const void* A, const void* W, void* C, const void* bias,
     static std::once_flag attr_once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(attr_once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, true, true, DMAV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     });
     D3D_HIP(attr_err);
-    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, true, true>), dim3(dp_tiles + tail * splits), dim3(T_THREADS), sh, s, (const uint16_t*)A,
+    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, true, true, DMAV>), dim3(dp_tiles + tail * splits), dim3(T_THREADS), sh, s, (const uint16_t*)A,
                        (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, dp_tiles,
                        splits, w->ws);
     hipLaunchKernelGGL((k_splitk_fixup<BF16, EPI>), dim3(tail * 8), dim3(T_THREADS), 0, s, (const float*)w->ws, (uint16_t*)C, (const uint16_t*)bias,
@@ -916,7 +1030,7 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
         const int64_t P = cu_count(), tn = N / TN, tiles = tm256 * tn, R = tiles % P;
         if (R > 0 && R * 2 <= P && R % tn == 0 && tm256 > R / tn) {
             const int64_t m1 = (tm256 - R / tn) * TM;
-            int32_t rc = d3d_gemm_nt_tile(A, W, C, bias, residual, (int32_t)m1, N, K, lda, ldw, ldc, dtype, epilogue, 257, stream);
+            int32_t rc = d3d_gemm_nt_tile(A, W, C, bias, residual, (int32_t)m1, N, K, lda, ldw, ldc, dtype, epilogue, gemm_loop_interleaved() ? 260 : 257, stream);
             if (rc != D3D_OK) return rc;
             const char* a8 = (const char*)A + m1 * lda * 2;
             char* c8 = (char*)C + m1 * ldc * 2;
@@ -925,6 +1039,7 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
         }
     }
     if (tile != 128) {
+        if (gemm_loop_interleaved()) tile = tile == 257 ? 260 : 264;
         int32_t rc = d3d_gemm_nt_tile(A, W, C, bias, residual, (int32_t)rows256, N, K, lda, ldw, ldc, dtype, epilogue, tile, stream);
         if (rc != D3D_OK || rows256 == M) return rc;
         const char* a8 = (const char*)A + rows256 * lda * 2;
@@ -939,7 +1054,7 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream) {
     if (M <= 0) return D3D_OK;
     if (tile == 16) return skinny_dispatch(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, dtype, epilogue, stream);
-    if (tile != 128 && tile != 130 && tile != 132 && (tile < 256 || tile > 259)) {
+    if (tile != 128 && tile != 130 && tile != 132 && (tile < 256 || (tile > 264 && (tile < 301 || tile > 303)))) {
         d3d_set_error_("d3d_gemm_nt_tile: tile must be 128 (130 / 132: 2 / 4 LDS stages forced), 256 (K-half steps), 257 (whole-K-tile steps) or 258 (257 + split-K tail)");
         return D3D_EINVAL;
     }
@@ -960,12 +1075,24 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
         if (tile == 258)                                                                                              \
             return dtype == 0 ? launch256_split<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)           \
                               : launch256_split<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);         \
+        if (tile == 264)                                                                                              \
+            return dtype == 0 ? launch256_split<true, E, 2>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)        \
+                              : launch256_split<false, E, 2>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);      \
         if (tile == 257)                                                                                              \
             return dtype == 0 ? launch256<true, E, true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)           \
                               : launch256<false, E, true>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);         \
         if (tile == 259)                                                                                              \
             return dtype == 0 ? launch256<true, E, true, 1>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)        \
                               : launch256<false, E, true, 1>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);      \
+        if (tile == 260)                                                                                              \
+            return dtype == 0 ? launch256<true, E, true, 2>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s)        \
+                              : launch256<false, E, true, 2>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);      \
+        if (tile == 301 && E == EPI_NONE) return launch256<true, EPI_NONE, true, 16>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);    \
+        if (tile == 302 && E == EPI_NONE) return launch256<true, EPI_NONE, true, 18>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);    \
+        if (tile == 303 && E == EPI_NONE) return launch256<true, EPI_NONE, true, 20>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s);    \
+        if (tile == 263 && E == EPI_NONE) return launch256<true, EPI_NONE, true, 5>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s); \
+        if (tile == 261 && E == EPI_NONE) return launch256<true, EPI_NONE, true, 3>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s); \
+        if (tile == 262 && E == EPI_NONE) return launch256<true, EPI_NONE, true, 4>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s); \
         return dtype == 0 ? launch<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s, tile == 128 ? 0 : tile - 128)  \
                           : launch<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s, tile == 128 ? 0 : tile - 128);
     switch (epilogue) {

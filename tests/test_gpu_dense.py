@@ -75,7 +75,7 @@ def test_gemm_epilogues_asymmetric(hd, dt, tol):
         assert rel(hd.linear(big[:, :K], w, None, None).float(), epi_ref("none", big[:, :K].float() @ w.float().t(), None, None, dt)) < tol
 
 
-@pytest.mark.parametrize("tile", [130, 132, 256, 257, 259])
+@pytest.mark.parametrize("tile", [130, 132, 256, 257, 259, 260])
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1e-3), (torch.float16, 2e-4)])
 def test_gemm_forced_tile_kernels(hd, dt, tol, tile):
     """Every kernel variant forced explicitly -- 128x128 with a 2- / 4-deep LDS ring (130 / 132), 256x256x64 staggered in
@@ -101,15 +101,16 @@ def test_gemm_forced_tile_kernels(hd, dt, tol, tile):
         HipDense.TILE = 0
 
 
+@pytest.mark.parametrize("tile", [258, 264])
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1e-3), (torch.float16, 2e-4)])
-def test_gemm_split_k_tail(hd, dt, tol):
-    """Tile code 258: whole rounds of 256x256 tiles data-parallel + the remainder tiles cut into K-slices whose fp32 partials a
+def test_gemm_split_k_tail(hd, dt, tol, tile):
+    """Tile codes 258 (staggered K loop) / 264 (interleaved K loop): whole rounds of 256x256 tiles data-parallel + the remainder tiles cut into K-slices whose fp32 partials a
     second launch sums in slice order.  Shapes: tail only (4, 44, 100 tiles -> 8, 5, 2 slices), rounds + tail, slices > K tiles,
     no tail at all; repeated launches reuse the workspace; results are bit-identical from launch to launch."""
     from dynam3d_amd.hip_dense import HipDense, interleave_gate_up
     torch.manual_seed(3)
     try:
-        HipDense.TILE = 258
+        HipDense.TILE = tile
         for M, N, K in ((512, 512, 1024), (2816, 1024, 2048), (6400, 1024, 512), (6400, 3072, 3072), (512, 512, 128), (4096, 4096, 256)):
             x = (torch.randn(M, K, device="cuda") * 0.7).to(dt)
             w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
