@@ -71,9 +71,12 @@ __device__ __forceinline__ float4v mfma16(const uint4& a, const uint4& b, float4
 template <bool BF16>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     if constexpr (BF16) {
-        uint32_t r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));      // RNE, one VALU op per pair (no builtin on gfx950)
-        return r;
+        // fptrunc <2 x float> -> <2 x bfloat> selects v_cvt_pk_bf16_f32 (RNE, NaN-safe); NOT inline asm: the hazard recogniser does not
+        // see through asm, and a conversion scheduled right behind the MFMA that produced its operand reads a stale register
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t r = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+        return *reinterpret_cast<const uint32_t*>(&r);
     } else {
         const __half2 h = __floats2half2_rn(lo, hi);
         return *reinterpret_cast<const uint32_t*>(&h);

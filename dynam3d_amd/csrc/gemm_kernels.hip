@@ -160,9 +160,12 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 template <bool BF16>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     if constexpr (BF16) {
-        uint32_t r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-        return r;
+        // fptrunc <2 x float> -> <2 x bfloat> selects v_cvt_pk_bf16_f32 (RNE, NaN-safe); NOT inline asm: the hazard recogniser does not
+        // see through asm, and a conversion scheduled right behind the MFMA that produced its operand reads a stale register
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t r = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+        return *reinterpret_cast<const uint32_t*>(&r);
     } else {
         const __half2 h = __floats2half2_rn(lo, hi);
         return *reinterpret_cast<const uint32_t*>(&h);
@@ -189,9 +192,12 @@ __device__ __forceinline__ void r16x4(float* v) {
     r16x2<BF16>(v[2], v[3]);
 }
 
-template <bool BF16, int EPI>
-__device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
-                                       const uint16_t* __restrict__ residual, int m, int n16, int fg, int64_t ldc) {
+// epi_pack: the epilogue arithmetic of four neighbouring outputs of one row, packed as 4 x 16 bit.  DEFER (the LDS-transposed epilogue of
+// the 256 x 256 kernel): the residual of EPI_RES / EPI_BIAS_RES is NOT added here -- the value returned is the linear's own 16-bit output
+// R(acc [+ bias]), the residual is added after the transposition with row-contiguous 16-byte loads (same rounding points).
+template <bool BF16, int EPI, bool DEFER>
+__device__ __forceinline__ uint2 epi_pack(const float4v& a, const float4v& b, const uint16_t* __restrict__ bias,
+                                          const uint16_t* __restrict__ residual, int m, int n16, int fg, int64_t ldc) {
     if constexpr (EPI == EPI_SWIGLU) {
         // HF Phi3MLP: gate_up = linear(x) [16-bit]; up * silu(gate) with silu's result and the product stored 16-bit
         float g[4] = {a[0], a[1], a[2], a[3]}, u[4] = {b[0], b[1], b[2], b[3]};
@@ -203,7 +209,7 @@ __device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint1
         uint2 o;
         o.x = pack2<BF16>(u[0] * g[0], u[1] * g[1]);
         o.y = pack2<BF16>(u[2] * g[2], u[3] * g[3]);
-        *reinterpret_cast<uint2*>(C + (int64_t)m * ldc + n16 / 2 + fg * 4) = o;
+        return o;
     } else {
         const int n = n16 + fg * 4;
         float v[4] = {a[0], a[1], a[2], a[3]};
@@ -240,7 +246,7 @@ __device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint1
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = to_f32<BF16>(hp[r]) > 0.f ? v[r] : 0.01f * v[r];
         }
-        if constexpr (EPI == EPI_RES || EPI == EPI_BIAS_RES) {
+        if constexpr ((EPI == EPI_RES || EPI == EPI_BIAS_RES) && !DEFER) {
             const uint2 rr = *reinterpret_cast<const uint2*>(residual + (int64_t)m * ldc + n);
             const uint16_t* rp = reinterpret_cast<const uint16_t*>(&rr);
             r16x4<BF16>(v);                                                          // x + linear(...): the linear's output is a 16-bit tensor
@@ -250,8 +256,23 @@ __device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint1
         uint2 o;
         o.x = pack2<BF16>(v[0], v[1]);
         o.y = pack2<BF16>(v[2], v[3]);
-        *reinterpret_cast<uint2*>(C + (int64_t)m * ldc + n) = o;
+        return o;
     }
+}
+
+template <bool BF16, int EPI>
+__device__ __forceinline__ void store4(const float4v& a, const float4v& b, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
+                                       const uint16_t* __restrict__ residual, int m, int n16, int fg, int64_t ldc) {
+    const uint2 o = epi_pack<BF16, EPI, false>(a, b, bias, residual, m, n16, fg, ldc);
+    const int n = EPI == EPI_SWIGLU ? n16 / 2 + fg * 4 : n16 + fg * 4;
+    *reinterpret_cast<uint2*>(C + (int64_t)m * ldc + n) = o;
+}
+
+// a + r on two packed 16-bit values each, rounded once (the residual add of the transposed epilogue)
+template <bool BF16>
+__device__ __forceinline__ uint32_t add2_16(uint32_t a, uint32_t r) {
+    return pack2<BF16>(to_f32<BF16>((uint16_t)(a & 0xffffu)) + to_f32<BF16>((uint16_t)(r & 0xffffu)),
+                       to_f32<BF16>((uint16_t)(a >> 16)) + to_f32<BF16>((uint16_t)(r >> 16)));
 }
 
 // NSTAGE = LDS K-tile ring depth.  2 (64 KiB, two workgroups per CU) is the throughput configuration; 4 (128 KiB, one
@@ -627,16 +648,49 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
         }
     }
 
+    if constexpr (EPI == EPI_LRELU_BWD) {          // (needs the activation in the accumulator layout: direct 8-byte stores; training only)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = row0 + grp * 128 + i * 16 + fi;
-        if (m >= M) continue;
-        if constexpr (EPI == EPI_SWIGLU) {
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) store4<BF16, EPI>(acc[i][j], acc[i][j + 1], C, bias, residual, m, col0 + wn * 64 + j * 16, fg, ldc);
-        } else {
+        for (int i = 0; i < 8; ++i) {
+            const int m = row0 + grp * 128 + i * 16 + fi;
+            if (m >= M) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) store4<BF16, EPI>(acc[i][j], acc[i][j], C, bias, residual, m, col0 + wn * 64 + j * 16, fg, ldc);
+        }
+    } else {
+        // Transposed epilogue.  In the accumulator layout a lane owns 4 neighbouring columns of one row, so a direct store instruction
+        // touches 16 rows x 32 B: 32 instructions per wave, ~8200 shader cycles per tile (cycle stamps, profiles/r02_gemm_cycle_stamps.txt:
+        // the same with ONE workgroup on the chip -- it is the CU's own store path, not the fabric).  Instead every wave packs its
+        // 128 x 64 sub-tile to 16 bit, parks it in its own 16 KiB of the (now idle) K-tile buffers -- ds_write_b64, 16-byte chunks
+        // XOR-swizzled by row -- and reads it back row-major: ds_read_b128 + global_store_dwordx4, 8 rows x 128 B per instruction
+        // (SwiGLU: 16 rows x 64 B).  The residual is added on the way out, loaded with the same row-contiguous 16-byte pattern.
+        __builtin_amdgcn_s_barrier();              // every wave is done reading the K-tile buffers
+        constexpr int RB = EPI == EPI_SWIGLU ? 64 : 128;     // bytes per sub-tile row
+        constexpr int LPR = RB / 16, RPP = 64 / LPR;         // lanes per row, rows per read-back pass
+        char* reg = reinterpret_cast<char*>(smem) + wave * (128 * RB);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = i * 16 + fi;
+            const int m = row0 + grp * 128 + row;
+#pragma unroll
+            for (int j = 0; j < 4; j += (EPI == EPI_SWIGLU ? 2 : 1)) {
+                const uint2 o = epi_pack<BF16, EPI, true>(acc[i][j], acc[i][EPI == EPI_SWIGLU ? j + 1 : j], bias, residual, m, col0 + wn * 64 + j * 16, fg, ldc);
+                const int cb = (EPI == EPI_SWIGLU ? j * 8 + fg * 4 : j * 16 + fg * 4) * 2;          // byte offset in the row
+                *reinterpret_cast<uint2*>(reg + row * RB + ((((cb >> 4) ^ row) & (LPR - 1)) << 4) + (cb & 15)) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS operations execute in order: its own writes are visible to its reads
+        const int ocol = (EPI == EPI_SWIGLU ? col0 / 2 + wn * 32 : col0 + wn * 64) + (lane % LPR) * 8;
+#pragma unroll
+        for (int p = 0; p < 128 / RPP; ++p) {
+            const int row = p * RPP + lane / LPR;
+            const int m = row0 + grp * 128 + row;
+            uint4 v = *reinterpret_cast<const uint4*>(reg + row * RB + ((((lane % LPR) ^ row) & (LPR - 1)) << 4));
+            if (m >= M) continue;
+            if constexpr (EPI == EPI_RES || EPI == EPI_BIAS_RES) {
+                const uint4 r = *reinterpret_cast<const uint4*>(residual + (int64_t)m * ldc + ocol);
+                v.x = add2_16<BF16>(v.x, r.x), v.y = add2_16<BF16>(v.y, r.y), v.z = add2_16<BF16>(v.z, r.z), v.w = add2_16<BF16>(v.w, r.w);
+            }
+            *reinterpret_cast<uint4*>(C + (int64_t)m * ldc + ocol) = v;
         }
     }
     if constexpr (TIMED) {
@@ -1015,9 +1069,11 @@ int32_t d3d_gemm_nt(const void* A, const void* W, void* C, const void* bias, con
     const int64_t rows256 = tm256 * TM < M ? tm256 * TM : M;
     const int64_t blocks256 = tm256 * (N / TN);
     int tile = 128;
-    if (N % TN == 0 && (blocks256 >= 768 || (blocks256 <= cu_count() && blocks256 * 4 >= cu_count() * 3))) {
+    // (the 256-tile kernels store 16 bytes per lane: C / residual rows must be 16-byte aligned)
+    const bool ok256 = N % TN == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (!residual || ((uintptr_t)residual & 15) == 0);
+    if (ok256 && (blocks256 >= 768 || (blocks256 <= cu_count() && blocks256 * 4 >= cu_count() * 3))) {
         tile = 257;               // several rounds, or one nearly full round (ViT qkv at M = 4616: 216 tiles, 41.6 us against 46.3 us)
-    } else if (N % TN == 0 && blocks256 >= 256) {
+    } else if (ok256 && blocks256 >= 256) {
         int dp_tiles, splits;
         split_plan((int)blocks256, K / BK, &dp_tiles, &splits);
         if (splits >= 3) tile = 258;
@@ -1058,8 +1114,8 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
         d3d_set_error_("d3d_gemm_nt_tile: tile must be 128 (130 / 132: 2 / 4 LDS stages forced), 256 (K-half steps), 257 (whole-K-tile steps) or 258 (257 + split-K tail)");
         return D3D_EINVAL;
     }
-    if (tile >= 256 && N % TN != 0) {
-        d3d_set_error_("d3d_gemm_nt_tile: the 256 x 256 tile needs N % 256 == 0");
+    if (tile >= 256 && (N % TN != 0 || (ldc & 7) || ((uintptr_t)C & 15) || (residual && ((uintptr_t)residual & 15)))) {
+        d3d_set_error_("d3d_gemm_nt_tile: the 256 x 256 tile needs N % 256 == 0, ldc % 8 == 0 and 16-byte aligned C / residual");
         return D3D_EINVAL;
     }
     if (N % BN != 0 || K % BK != 0 || (lda & 7) || (ldw & 7) || (ldc & 3)) {

@@ -24,9 +24,8 @@ __device__ __forceinline__ float ld16(uint16_t v) {
 template <bool BF16>
 __device__ __forceinline__ uint16_t st16(float f) {
     if constexpr (BF16) {
-        uint32_t r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(f));      // hardware RNE (NaN-safe); one VALU operation
-        return (uint16_t)r;
+        const __bf16 r = (__bf16)f;                  // fptrunc selects the hardware converter (v_cvt_pk_bf16_f32: RNE, NaN-safe)
+        return *reinterpret_cast<const uint16_t*>(&r);
     } else {
         __half h = __float2half_rn(f);
         return *reinterpret_cast<uint16_t*>(&h);
