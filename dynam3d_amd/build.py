@@ -25,6 +25,7 @@ HIP_SOURCES = [
     ("f32_kernels.hip", ["-ffp-contract=off"]),
     ("gemm_kernels.hip", ["-ffp-contract=fast"]),
     ("attn_kernels.hip", ["-ffp-contract=fast"]),
+    ("decode_kernels.hip", ["-ffp-contract=fast"]),
     ("render_kernels.hip", ["-ffp-contract=off"]),
 ]
 CPP_SOURCES = ["ff_state.cpp", "d3d_error.cpp", "phi3_decode.cpp", "mlp_forward.cpp"]

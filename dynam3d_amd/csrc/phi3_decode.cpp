@@ -8,6 +8,9 @@
 #include "../../include/dynam3d_hip.h"
 
 extern "C" void d3d_set_error_(const char* msg);
+// decode_kernels.hip: the whole token as ONE cooperative launch (persistent workgroups, grid barriers between the phases)
+extern "C" int32_t d3d_phi3_decode_persistent_ok(const d3d_phi3_decode_args* a);
+extern "C" int32_t d3d_phi3_decode_token_persistent(const d3d_phi3_decode_args* a);
 
 extern "C" int32_t d3d_phi3_decode_token(const d3d_phi3_decode_args* a) {
     if (!a || a->n_layers <= 0 || a->rows <= 0) return D3D_OK;
@@ -17,6 +20,7 @@ extern "C" int32_t d3d_phi3_decode_token(const d3d_phi3_decode_args* a) {
         d3d_set_error_("d3d_phi3_decode_token: needs heads * head_dim == hidden (no grouped-query attention) and rows <= 16");
         return D3D_EINVAL;
     }
+    if (d3d_phi3_decode_persistent_ok(a)) return d3d_phi3_decode_token_persistent(a);      // (D3D_DECODE_PERSISTENT=0: the launch-per-op path below)
     void* s = a->stream;
     void* x = a->x;                       // (rows, hidden) in / out: the residual stream
     int32_t rc;

@@ -22,6 +22,7 @@ _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
 _lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
 _lib.register("d3d_decode_attention", [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp])
 _lib.register("d3d_phi3_decode_token", [vp])
+_lib.register("d3d_phi3_decode_status", [vp])
 _lib.register("d3d_patchify", [vp, vp, i32, i32, i32, i32, i32, vp])
 _lib.register("d3d_vit_embed_ln", [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp])
 
@@ -155,6 +156,10 @@ class HipDense:
         """All launches of one KV-cache decode token, issued from C++ (d3d_phi3_decode_token)."""
         args.stream = self._stream()
         _lib.check(self.lib.d3d_phi3_decode_token(C.byref(args)))
+
+    def phi3_decode_status(self):
+        """Synchronises the stream and raises if a grid barrier of the persistent decode kernel timed out (d3d_phi3_decode_status)."""
+        _lib.check(self.lib.d3d_phi3_decode_status(self._stream()))
 
     def patchify(self, pixels, patch, Kp, dtype):
         """pixels (B,3,S,S) f32 -> (B*(S/patch)^2, Kp) rows of unfolded patches in `dtype`, zero-padded columns (d3d_patchify)."""

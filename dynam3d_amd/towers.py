@@ -396,6 +396,8 @@ class Phi3Decoder:
             if run is None:
                 run = self._decode_runner(B, kv, cu, side, cos, sin, max(lens))
             logits = run(xt, pos, i)
+        if run is not None:
+            run.status()                                                          # (synchronises: the persistent decode kernel's error flag)
         tok_h = torch.stack(toks).tolist()                                        # (steps, B), one transfer
         gen = []
         for b in range(B):
@@ -438,6 +440,7 @@ class Phi3Decoder:
             a.x, a.pos, a.t_new = x.data_ptr(), pos.data_ptr(), t_new
             hdn.phi3_decode_token(a)
             return buf["logits"].float() if keep else None
+        run.status = hdn.phi3_decode_status
         return run
 
     @torch.no_grad()

@@ -295,6 +295,11 @@ typedef struct d3d_phi3_decode_args {
     void* stream;
 } d3d_phi3_decode_args;
 int32_t d3d_phi3_decode_token(const d3d_phi3_decode_args* args);
+/* llava-phi-3-mini's decoder (hidden 3072, mlp 8192, head_dim 96) at <= 8 rows runs as ONE cooperative launch per token (persistent
+ * workgroups, grid barriers between the phases: csrc/decode_kernels.hip; D3D_DECODE_PERSISTENT=0 keeps the launch-per-op path).  A
+ * grid barrier that times out raises a sticky per-stream flag instead of hanging the device; d3d_phi3_decode_status synchronises the
+ * stream and reports it (D3D_EHIP) -- call it once per generation, after the last token. */
+int32_t d3d_phi3_decode_status(void* stream);
 
 /* One decode step of causal self-attention with a KV cache -- the `use_cache` branch of the HF Phi-3 attention under
  * `llava.generate(max_new_tokens=20, do_sample=False)` (VLN-POL:463).  qkv_new (B, 3H, hd): this step's fused projection (before
