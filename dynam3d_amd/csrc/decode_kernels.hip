@@ -48,7 +48,8 @@ using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 struct DecP {
     int n_layers, rows, heads, vocab, t_new, t_max;
     float eps, scale;
-    uint16_t *x, *qkv, *attn, *act, *logits;
+    uint16_t *x, *logits;
+    uint16_t* ws;                         // per-layer scratch: [L] qkv (8, 3H) | [L] attn (8, H) | [L] act (8, MLP) | [2L] x (8, H)
     const uint16_t* qkv_w[MAXL];
     const uint16_t* o_w[MAXL];
     const uint16_t* gu_w[MAXL];
@@ -62,8 +63,9 @@ struct DecP {
     const int32_t *pos, *cu;
     uint16_t *knew, *vnew;
     int64_t cache_layer_stride;           // elements
-    unsigned* bar;                        // [0] arrival counter, [1] error flag
-    int debug;                            // D3D_DECODE_DEBUG bits (timing experiments, WRONG results): 1 no barrier wait, 2 no acquire fence, 4 no attention, 8 no GEMM tiles
+    unsigned* bar;                        // flags[grid] arrival epochs, [BAR_ERR] error flag
+    int debug;                            // D3D_DECODE_DEBUG bits (experiments; 1, 4, 8 give WRONG results): 1 no barrier wait, 2 + acquire fence, 4 no attention,
+                                          // 8 no GEMM tiles, 16 agent-scope activation loads, 32 phase stamps
 };
 
 __device__ __forceinline__ void st_agent(uint16_t* p, uint2 v) {
@@ -93,36 +95,56 @@ __device__ __forceinline__ void issue_w(u32x4 (&wb)[32], const uint16_t* __restr
     }
 }
 
-// Data that crosses workgroups (qkv, attn, x, act) is stored WRITE-THROUGH (st_agent: relaxed agent-scope atomic stores, sc1), so arriving
-// only has to wait for this wave's stores to be acknowledged (s_waitcnt).  An agent-scope release FENCE would write the whole L2 back
-// (buffer_wbl2) from every wave of every workgroup at every barrier: measured 14 ms per token instead of 3.8.
-__device__ __forceinline__ void bar_arrive(unsigned* bar) {
+// Grid barrier over flags, not a counter.  Data that crosses workgroups (qkv, attn, x, act) is stored WRITE-THROUGH (st_agent: relaxed
+// agent-scope atomic stores, sc1), so no cache maintenance is needed when arriving:
+//   arrive: every wave waits for its stores (s_waitcnt), the workgroup syncs, thread 0 stores the epoch into ITS slot flags[block];
+//   wait  : thread t polls flags[t] (one coalesced read of the whole array per round) until every slot carries the epoch.
+// Measured on the way here (ms per token, 161 barriers): agent-scope release fence from every wave (buffer_wbl2: writes the whole L2
+// back) 14.3; one counter + atomic add per workgroup + agent-scope acquire fence (buffer_inv) 7.1, of which 3.0 waiting on the
+// counter (256 read-modify-writes of one address queue up at the memory side) and 2.0 in the invalidates; flags + agent-scope loads 4.2.
+constexpr int BAR_ERR = 1024;             // flags[0 .. grid): arrival epochs; flags[BAR_ERR]: sticky error flag
+
+__device__ __forceinline__ void bar_arrive(unsigned* flags, unsigned epoch) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // false = the kernel is unwinding (some workgroup gave up waiting): uniform over the workgroup
-__device__ __forceinline__ bool bar_wait(unsigned* bar, unsigned target, int* flag_lds, int debug) {
+__device__ __forceinline__ bool bar_wait(unsigned* flags, unsigned epoch, int debug) {
     if (debug & 1) return true;
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
+    const int G = gridDim.x;
+    unsigned spins = 0;
+    for (;;) {
         int ok = 1;
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-            if (++spins > (1u << 21)) {                          // ~seconds: co-residency lost or a workgroup died
-                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
+        for (int t = threadIdx.x; t < G; t += DT) ok &= __hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+        if (__syncthreads_and(ok)) break;
+        int bad = 0;
+        if (threadIdx.x == 0) {
+            bad = __hip_atomic_load(flags + BAR_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (++spins > (1u << 20)) {                          // ~seconds: co-residency lost or a workgroup died
+                __hip_atomic_store(flags + BAR_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad = 1;
             }
         }
-        *flag_lds = ok;
+        if (__syncthreads_or(bad)) return false;
     }
-    __syncthreads();
-    const bool ok = *flag_lds != 0;
-    if (!(debug & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // other workgroups' stores are visible from here on
-    return ok;
+    if (debug & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (experiment: the invalidate the per-layer buffers make unnecessary)
+    return true;
+}
+
+// Cross-workgroup activations live in PER-LAYER scratch buffers (DecP::ws): an address is written once and read only after the barrier
+// that follows, so no cache of any XCD can hold an older copy of it -- the kernel's launch invalidated them, and nothing read the line
+// since.  The first workgroup of an XCD that touches a line pulls it from memory, the other 31 hit that XCD's L2 (plain 16-byte loads).
+// With ONE buffer per tensor (reused by every layer) the loads have to be agent-scope (8-byte, every workgroup all the way to memory):
+// debug bit 16 keeps those for comparison (4.11 against 4.01 ms per token).
+__device__ __forceinline__ uint4 ld_agent16(const uint16_t* p) {
+    const uint64_t lo = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t hi = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+__device__ __forceinline__ uint4 ld_x16(const uint16_t* p, bool agent) {
+    return agent ? ld_agent16(p) : *reinterpret_cast<const uint4*>(p);
 }
 
 __device__ __forceinline__ float wave_sum64(float v) {
@@ -134,7 +156,7 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // RMSNorm of the <= 8 rows of x (global) into LDS rows of HID + 8: wave w = row w, the lane / chunk order of k_norm (dense_kernels.hip),
 // so the normalised rows are bit-identical to d3d_norm's.  HF Phi3RMSNorm: weight * x_hat.to(dtype).
 template <bool BF16, int HID>
-__device__ __forceinline__ void norm_stage(const uint16_t* __restrict__ x, const float* __restrict__ w, uint16_t* xs, int M, float eps) {
+__device__ __forceinline__ void norm_stage(const uint16_t* x, const float* __restrict__ w, uint16_t* xs, int M, float eps, bool agent) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NCH = HID / 512;
     if (wave < M) {
@@ -143,7 +165,7 @@ __device__ __forceinline__ void norm_stage(const uint16_t* __restrict__ x, const
         float ss = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(xr + c * 512 + lane * 8);
+            const uint4 raw = ld_x16(xr + c * 512 + lane * 8, agent);
             const uint16_t* h = reinterpret_cast<const uint16_t*>(&raw);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -174,7 +196,7 @@ __device__ __forceinline__ void norm_stage(const uint16_t* __restrict__ x, const
 
 // rows of `src` (global, width W elements) -> LDS rows of W + 8 (eight 16-byte chunks per thread in flight)
 template <int W>
-__device__ __forceinline__ void stage_x(const uint16_t* __restrict__ src, uint16_t* xs, int M) {
+__device__ __forceinline__ void stage_x(const uint16_t* src, uint16_t* xs, int M, bool agent) {
     constexpr int CPR = W / 8;                          // 16-byte chunks per row
     const int total = M * CPR;
     for (int q0 = threadIdx.x; q0 < total; q0 += 8 * DT) {
@@ -182,7 +204,7 @@ __device__ __forceinline__ void stage_x(const uint16_t* __restrict__ src, uint16
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int q = q0 + i * DT;
-            if (q < total) v[i] = *reinterpret_cast<const uint4*>(src + (int64_t)q * 8);
+            if (q < total) v[i] = ld_x16(src + (int64_t)q * 8, agent);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -242,7 +264,7 @@ __device__ __forceinline__ void gemm_phase(u32x4 (&wb)[32], bool& have, const ui
 // Phase B for one (sequence b, head h): RoPE of the new q / k (HF apply_rotary_pos_emb on 16-bit tensors, like k_rope), k / v appended
 // to the side cache, softmax(q K^T) V over prompt rows (read in place from the prefill's post-RoPE QKV buffer) + generated tokens.
 template <bool BF16, int HD>
-__device__ __forceinline__ void attend(const DecP& p, int layer, int b, int h, uint8_t* lds) {
+__device__ __forceinline__ void attend(const DecP& p, int layer, int b, int h, uint8_t* lds, const uint16_t* qkv_new, uint16_t* attn_out, bool agent) {
     float* qs = reinterpret_cast<float*>(lds);                          // [HD]
     uint16_t* kcur = reinterpret_cast<uint16_t*>(lds + 512);            // [HD]
     float* red = reinterpret_cast<float*>(lds + 1024);                  // [16]
@@ -250,14 +272,21 @@ __device__ __forceinline__ void attend(const DecP& p, int layer, int b, int h, u
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, H = p.heads;
     const int64_t rs = (int64_t)3 * H * HD;
     const int r0 = p.cu[b], S = p.cu[b + 1] - r0, L = S + p.t_new + 1;
-    const uint16_t* qrow = p.qkv + (int64_t)b * rs + (int64_t)h * HD;
+    const uint16_t* qrow = qkv_new + (int64_t)b * rs + (int64_t)h * HD;
     const uint16_t* prompt = p.prompt_qkv[layer];
     uint16_t* knew = p.knew + (int64_t)layer * p.cache_layer_stride;
     uint16_t* vnew = p.vnew + (int64_t)layer * p.cache_layer_stride;
     constexpr int HALF = HD / 2;
+    // this token's q, k, v rows were written by other workgroups in phase A -> LDS
+    uint16_t* nq = reinterpret_cast<uint16_t*>(lds + 1152);             // [3][HD]
+    if (tid < 3 * (HD / 8)) {
+        const int part = tid / (HD / 8), c = tid % (HD / 8);
+        *reinterpret_cast<uint4*>(nq + part * HD + c * 8) = ld_x16(qrow + (int64_t)part * H * HD + c * 8, agent);
+    }
+    __syncthreads();
     if (tid < HALF) {
-        float q1 = to_f32<BF16>(qrow[tid]), q2 = to_f32<BF16>(qrow[tid + HALF]);
-        float k1 = to_f32<BF16>(qrow[(int64_t)H * HD + tid]), k2 = to_f32<BF16>(qrow[(int64_t)H * HD + tid + HALF]);
+        float q1 = to_f32<BF16>(nq[tid]), q2 = to_f32<BF16>(nq[tid + HALF]);
+        float k1 = to_f32<BF16>(nq[HD + tid]), k2 = to_f32<BF16>(nq[HD + tid + HALF]);
         const float c = p.cos_t[(int64_t)p.pos[b] * HALF + tid], sn = p.sin_t[(int64_t)p.pos[b] * HALF + tid];
         auto r = [](float f) { return to_f32<BF16>((uint16_t)pack2<BF16>(f, 0.f)); };
         const uint32_t qp = pack2<BF16>(r(q1 * c) - r(q2 * sn), r(q2 * c) + r(q1 * sn));
@@ -271,113 +300,112 @@ __device__ __forceinline__ void attend(const DecP& p, int layer, int b, int h, u
         kd[tid + HALF] = (uint16_t)(kp >> 16);
     } else if (tid >= 64 && tid < 64 + HD / 8) {
         const int c = tid - 64;
-        *reinterpret_cast<uint4*>(vnew + (((int64_t)b * p.t_max + p.t_new) * H + h) * HD + c * 8) =
-            *reinterpret_cast<const uint4*>(qrow + (int64_t)2 * H * HD + c * 8);
+        *reinterpret_cast<uint4*>(vnew + (((int64_t)b * p.t_max + p.t_new) * H + h) * HD + c * 8) = *reinterpret_cast<const uint4*>(nq + 2 * HD + c * 8);
     }
     __syncthreads();
-    auto krow = [&](int j) -> const uint16_t* {
+    auto krow = [&](int j) -> const uint16_t* {                                   // keys / values 0 .. L-2 (L-1 = this token: LDS)
         if (j < S) return prompt + (int64_t)(r0 + j) * rs + (int64_t)(H + h) * HD;
-        return knew + (((int64_t)b * p.t_max + (j - S)) * H + h) * HD;          // (j == L-1 is served from LDS)
+        return knew + (((int64_t)b * p.t_max + (j - S)) * H + h) * HD;
     };
     auto vrow = [&](int j) -> const uint16_t* {
         if (j < S) return prompt + (int64_t)(r0 + j) * rs + (int64_t)(2 * H + h) * HD;
-        if (j == L - 1) return qrow + (int64_t)2 * H * HD;
         return vnew + (((int64_t)b * p.t_max + (j - S)) * H + h) * HD;
     };
-    // ---- scores: 16 lanes per key (HD/8 of them carry a 16-byte chunk: one key row = one contiguous 2*HD-byte read), 8 keys in flight
-    constexpr int CH = HD / 8;
+    // ---- ONE pass over the keys (flash-decoding): 16 lanes per key, HD/8 of them carry a 16-byte chunk of the key row AND of the value
+    //      row (one row = one contiguous 2*HD-byte read), 8 keys = 16 loads in flight per lane.  Every lane group keeps a running
+    //      (max, sum, output chunk) with the usual rescaling; the 32 groups' partial results are merged in LDS in group order.
+    constexpr int CH = HD / 8, NGRP = DT / 16;
     const int kg = tid >> 4, kc = tid & 15;
+    const bool act = kc < CH;
     float qreg[8];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) qreg[d] = kc < CH ? qs[kc * 8 + d] : 0.f;
-    float tmax = -INFINITY;
-    for (int j0 = kg; j0 < L; j0 += 8 * (DT / 16)) {
-        uint4 kv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = j0 + u * (DT / 16);
-            kv[u] = make_uint4(0, 0, 0, 0);
-            if (j < L && kc < CH) kv[u] = j == L - 1 ? *reinterpret_cast<const uint4*>(kcur + kc * 8) : *reinterpret_cast<const uint4*>(krow(j) + kc * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = j0 + u * (DT / 16);
-            const uint16_t* e = reinterpret_cast<const uint16_t*>(&kv[u]);
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) s += qreg[d] * to_f32<BF16>(e[d]);
-            s += __shfl_xor(s, 8);
-            s += __shfl_xor(s, 4);
-            s += __shfl_xor(s, 2);
-            s += __shfl_xor(s, 1);
-            if (j < L) {
-                if (kc == 0) sc[j] = s;
-                tmax = fmaxf(tmax, s);
-            }
-        }
-    }
-#pragma unroll
-    for (int w = 32; w >= 1; w >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, w));
-    if (lane == 0) red[wave] = tmax;
-    __syncthreads();
-    float m = red[0];
-#pragma unroll
-    for (int q = 1; q < DT / 64; ++q) m = fmaxf(m, red[q]);
-    float lsum = 0.f;
-    for (int j = tid; j < L; j += DT) {
-        const float pr = __expf(sc[j] - m);
-        sc[j] = pr;
-        lsum += pr;
-    }
-    lsum = wave_sum64(lsum);
-    if (lane == 0) red[8 + wave] = lsum;
-    __syncthreads();
-    float tot = 0.f;
-#pragma unroll
-    for (int q = 0; q < DT / 64; ++q) tot += red[8 + q];
-    const float inv = 1.0f / tot;
-    // ---- O = P V: thread = (key group g, 16-byte chunk c of the value row), eight keys in flight, partial sums meet in LDS
-    constexpr int NG = DT / CH;
+    for (int d = 0; d < 8; ++d) qreg[d] = act ? qs[kc * 8 + d] : 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int g = tid / CH, c = tid % CH;
-    if (g < NG) {
-        int j = g;
-        for (; j + 7 * NG < L; j += 8 * NG) {
-            uint4 v[8];
-            float pr[8];
+    auto fold = [&](const uint4 (&kv)[8], const uint4 (&vv)[8], int nvalid) {
+        float sv[8];
+        float bm = -INFINITY;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                v[u] = *reinterpret_cast<const uint4*>(vrow(j + u * NG) + c * 8);
-                pr[u] = sc[j + u * NG];
-            }
+        for (int u = 0; u < 8; ++u) {
+            const uint16_t* e = reinterpret_cast<const uint16_t*>(&kv[u]);
+            float t = 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint16_t* e = reinterpret_cast<const uint16_t*>(&v[u]);
+            for (int d = 0; d < 8; ++d) t += qreg[d] * to_f32<BF16>(e[d]);
+            t += __shfl_xor(t, 8);
+            t += __shfl_xor(t, 4);
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 1);
+            sv[u] = u < nvalid ? t : -INFINITY;
+            bm = fmaxf(bm, sv[u]);
+        }
+        const float m_new = fmaxf(m_run, bm);
+        const float resc = __expf(m_run - m_new);               // (first block: exp(-inf) = 0)
+        l_run *= resc;
 #pragma unroll
-                for (int d = 0; d < 8; ++d) o[d] += pr[u] * to_f32<BF16>(e[d]);
+        for (int d = 0; d < 8; ++d) o[d] *= resc;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float pe = __expf(sv[u] - m_new);             // invalid slots: exp(-inf) = 0
+            l_run += pe;
+            const uint16_t* e = reinterpret_cast<const uint16_t*>(&vv[u]);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) o[d] += pe * to_f32<BF16>(e[d]);
+        }
+        m_run = m_new;
+    };
+    for (int j0 = kg; j0 < L - 1; j0 += 8 * NGRP) {
+        uint4 kv[8], vv[8];
+        int nvalid = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * NGRP;
+            kv[u] = make_uint4(0, 0, 0, 0);
+            vv[u] = make_uint4(0, 0, 0, 0);
+            if (j < L - 1) {
+                nvalid = u + 1;
+                if (act) {
+                    kv[u] = *reinterpret_cast<const uint4*>(krow(j) + kc * 8);
+                    vv[u] = *reinterpret_cast<const uint4*>(vrow(j) + kc * 8);
+                }
             }
         }
-        for (; j < L; j += NG) {
-            const uint4 v = *reinterpret_cast<const uint4*>(vrow(j) + c * 8);
-            const float pr = sc[j];
-            const uint16_t* e = reinterpret_cast<const uint16_t*>(&v);
-#pragma unroll
-            for (int d = 0; d < 8; ++d) o[d] += pr * to_f32<BF16>(e[d]);
-        }
+        fold(kv, vv, nvalid);
     }
-    __syncthreads();                                    // every thread is done with sc[] as probabilities
-    if (g < NG) {
+    if (kg == 0) {                                                   // this token's own key / value: LDS copies
+        uint4 kv[8], vv[8];
 #pragma unroll
-        for (int d = 0; d < 8; ++d) sc[g * HD + c * 8 + d] = o[d];
+        for (int u = 0; u < 8; ++u) kv[u] = vv[u] = make_uint4(0, 0, 0, 0);
+        if (act) {
+            kv[0] = *reinterpret_cast<const uint4*>(kcur + kc * 8);
+            vv[0] = *reinterpret_cast<const uint4*>(nq + 2 * HD + kc * 8);
+        }
+        fold(kv, vv, 1);
+    }
+    // ---- merge the groups: sc = [NGRP] max | [NGRP] sum | [NGRP][HD] outputs
+    float* gm = sc;
+    float* gl = sc + NGRP;
+    float* go = sc + 2 * NGRP;
+    if (kc == 0) {
+        gm[kg] = m_run;
+        gl[kg] = l_run;
+    }
+    if (act) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) go[kg * HD + kc * 8 + d] = o[d];
     }
     __syncthreads();
     if (tid < HD / 2) {
-        float a0 = 0.f, a1 = 0.f;
-        for (int q = 0; q < NG; ++q) {                  // fixed order: deterministic
-            a0 += sc[q * HD + 2 * tid];
-            a1 += sc[q * HD + 2 * tid + 1];
+        float mx = gm[0];
+        for (int g = 1; g < NGRP; ++g) mx = fmaxf(mx, gm[g]);
+        float lt = 0.f, a0 = 0.f, a1 = 0.f;
+        for (int g = 0; g < NGRP; ++g) {                          // fixed order: deterministic
+            const float wgt = __expf(gm[g] - mx);                 // (a group that saw no key: exp(-inf) = 0)
+            lt += gl[g] * wgt;
+            a0 += go[g * HD + 2 * tid] * wgt;
+            a1 += go[g * HD + 2 * tid + 1] * wgt;
         }
-        st_agent(p.attn + ((int64_t)b * H + h) * HD + 2 * tid, pack2<BF16>(a0 * inv, a1 * inv));
+        const float inv = 1.0f / lt;
+        st_agent(attn_out + ((int64_t)b * H + h) * HD + 2 * tid, pack2<BF16>(a0 * inv, a1 * inv));
     }
     __syncthreads();
 }
@@ -388,7 +416,6 @@ __global__ void __launch_bounds__(DT, 2) k_phi3_decode_token(const DecP p) {
     constexpr int XS_BYTES = 8 * (MLP + 8) * 2;
     uint16_t* xs = reinterpret_cast<uint16_t*>(lds);                                    // staged activations (or phase B's scratch)
     float4v* red = reinterpret_cast<float4v*>(lds + XS_BYTES);                           // [8 waves][2][64] partial accumulators
-    int* flag = reinterpret_cast<int*>(lds + XS_BYTES + (DT / 64) * 2 * 64 * 16);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fi = lane & 15, fg = lane >> 4;
     const int M = p.rows, G = gridDim.x, bid = blockIdx.x;
     constexpr int KS_H = HID / 32 / (DT / 64), KS_M = MLP / 32 / (DT / 64);             // K steps per wave: 12 (K = hidden), 32 (K = mlp)
@@ -396,16 +423,39 @@ __global__ void __launch_bounds__(DT, 2) k_phi3_decode_token(const DecP p) {
     bool have = false;
     unsigned target = 0;
 #define D3D_GRID_BARRIER(...)                                   \
-    bar_arrive(p.bar);                                          \
+    target += 1u;                                               \
+    bar_arrive(p.bar, target);                                  \
     __VA_ARGS__;                                                \
-    target += (unsigned)G;                                      \
-    if (!bar_wait(p.bar, target, flag, p.debug)) return;
+    if (!bar_wait(p.bar, target, p.debug)) return;
 
-    for (int l = 0; l < p.n_layers; ++l) {
+    const bool agent = (p.debug & 16) != 0;
+    const int L = p.n_layers;
+    // debug bit 32: workgroups 0 and G-1 stamp the constant 100 MHz counter at every phase boundary of layer 5 (flags + 1280 / + 1312)
+    const bool stamping = (p.debug & 32) && (bid == 0 || bid == G - 1) && threadIdx.x == 0;
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.bar + 1280 + (bid == 0 ? 0 : 32));
+    int stamp_i = 0;
+#define D3D_STAMP() if (stamping && l == 5) stamps[stamp_i++] = __builtin_amdgcn_s_memrealtime();
+    uint16_t* const ws_qkv = p.ws;
+    uint16_t* const ws_attn = ws_qkv + (int64_t)L * 8 * 3 * HID;
+    uint16_t* const ws_act = ws_attn + (int64_t)L * 8 * HID;
+    uint16_t* const ws_x = ws_act + (int64_t)L * 8 * MLP;
+    const uint16_t* xin = p.x;                                    // the residual stream entering the layer
+    for (int l = 0; l < L; ++l) {
+        uint16_t* const qkv = ws_qkv + (int64_t)l * 8 * 3 * HID;
+        uint16_t* const attn = ws_attn + (int64_t)l * 8 * HID;
+        uint16_t* const act = ws_act + (int64_t)l * 8 * MLP;
+        uint16_t* const xmid = ws_x + (int64_t)(2 * l) * 8 * HID;                             // after attention
+        uint16_t* const xout = l + 1 < L ? ws_x + (int64_t)(2 * l + 1) * 8 * HID : p.x;       // after the MLP (last layer: the caller's x)
+        const uint16_t* const nextw = l + 1 < L ? p.qkv_w[l + 1] : p.lm_head;                // the GEMM after this layer's down_proj
+        const int nextn = l + 1 < L ? 3 * HID / 16 : p.vocab / 16;
+        D3D_STAMP()
         // ---- A: input RMSNorm + qkv projection
-        norm_stage<BF16, HID>(p.x, p.n1[l], xs, M, p.eps);
-        gemm_phase<BF16, KS_H, false, EPI_NONE>(wb, have, p.qkv_w[l], HID, 3 * HID / 16, xs, HID + 8, M, red, p.qkv, nullptr, 3 * HID, p.debug);
+        norm_stage<BF16, HID>(xin, p.n1[l], xs, M, p.eps, agent);
+        D3D_STAMP()
+        gemm_phase<BF16, KS_H, false, EPI_NONE>(wb, have, p.qkv_w[l], HID, 3 * HID / 16, xs, HID + 8, M, red, qkv, nullptr, 3 * HID, p.debug);
+        D3D_STAMP()
         D3D_GRID_BARRIER(if (bid < HID / 16) { issue_w<KS_H, false>(wb, p.o_w[l], HID, bid, wave, fi, fg); have = true; })
+        D3D_STAMP()
         // ---- B: attention, one (sequence, head) per workgroup; pairs of heads that share 128-byte lines of a K/V row land on one XCD
         {
             const int items = M * p.heads;
@@ -415,34 +465,46 @@ __global__ void __launch_bounds__(DT, 2) k_phi3_decode_token(const DecP p) {
                     const int base = it / G * G, j = it - base, q = (j & 7) + 8 * (j >> 4);
                     gh = base + 2 * q + ((j >> 3) & 1);          // (a bijection on every round: items and G are multiples of 16)
                 }
-                if (!(p.debug & 4)) attend<BF16, HD>(p, l, gh / p.heads, gh % p.heads, lds);
+                if (!(p.debug & 4)) attend<BF16, HD>(p, l, gh / p.heads, gh % p.heads, lds, qkv, attn, agent);
             }
         }
+        D3D_STAMP()
         D3D_GRID_BARRIER((void)0)
-        // ---- C: o_proj + residual (in place on x)
-        stage_x<HID>(p.attn, xs, M);
-        gemm_phase<BF16, KS_H, false, EPI_RES>(wb, have, p.o_w[l], HID, HID / 16, xs, HID + 8, M, red, p.x, p.x, HID, p.debug);
+        D3D_STAMP()
+        // ---- C: o_proj + residual
+        stage_x<HID>(attn, xs, M, agent);
+        D3D_STAMP()
+        gemm_phase<BF16, KS_H, false, EPI_RES>(wb, have, p.o_w[l], HID, HID / 16, xs, HID + 8, M, red, xmid, xin, HID, p.debug);
+        D3D_STAMP()
         D3D_GRID_BARRIER(if (bid < MLP / 16) { issue_w<KS_H, true>(wb, p.gu_w[l], HID, bid, wave, fi, fg); have = true; })
+        D3D_STAMP()
         // ---- D: post-attention RMSNorm + gate_up projection + SwiGLU (weights interleaved per 16 rows: gate tile, up tile)
-        norm_stage<BF16, HID>(p.x, p.n2[l], xs, M, p.eps);
-        gemm_phase<BF16, KS_H, true, EPI_SWIGLU>(wb, have, p.gu_w[l], HID, MLP / 16, xs, HID + 8, M, red, p.act, nullptr, MLP, p.debug);
+        norm_stage<BF16, HID>(xmid, p.n2[l], xs, M, p.eps, agent);
+        D3D_STAMP()
+        gemm_phase<BF16, KS_H, true, EPI_SWIGLU>(wb, have, p.gu_w[l], HID, MLP / 16, xs, HID + 8, M, red, act, nullptr, MLP, p.debug);
+        D3D_STAMP()
         D3D_GRID_BARRIER(if (bid < HID / 16) { issue_w<KS_M, false>(wb, p.down_w[l], MLP, bid, wave, fi, fg); have = true; })
+        D3D_STAMP()
         // ---- E: down_proj + residual
-        stage_x<MLP>(p.act, xs, M);
-        gemm_phase<BF16, KS_M, false, EPI_RES>(wb, have, p.down_w[l], MLP, HID / 16, xs, MLP + 8, M, red, p.x, p.x, HID, p.debug);
-        {
-            const uint16_t* nw = l + 1 < p.n_layers ? p.qkv_w[l + 1] : p.lm_head;
-            const int nt = l + 1 < p.n_layers ? 3 * HID / 16 : p.vocab / 16;
-            D3D_GRID_BARRIER(if (bid < nt) { issue_w<KS_H, false>(wb, nw, HID, bid, wave, fi, fg); have = true; })
-        }
+        stage_x<MLP>(act, xs, M, agent);
+        D3D_STAMP()
+        gemm_phase<BF16, KS_M, false, EPI_RES>(wb, have, p.down_w[l], MLP, HID / 16, xs, MLP + 8, M, red, xout, xmid, HID, p.debug);
+        D3D_STAMP()
+        D3D_GRID_BARRIER(if (bid < nextn) { issue_w<KS_H, false>(wb, nextw, HID, bid, wave, fi, fg); have = true; })
+        D3D_STAMP()
+        xin = xout;
     }
-    norm_stage<BF16, HID>(p.x, p.norm_w, xs, M, p.eps);
+    // the final hidden state sits in the caller's x: this workgroup read that buffer as layer 0's input, so -- like everything a second
+    // read could find stale -- it is read with agent-scope loads
+    norm_stage<BF16, HID>(p.x, p.norm_w, xs, M, p.eps, true);
     gemm_phase<BF16, KS_H, false, EPI_NONE>(wb, have, p.lm_head, HID, p.vocab / 16, xs, HID + 8, M, red, p.logits, nullptr, p.vocab, p.debug);
 #undef D3D_GRID_BARRIER
+#undef D3D_STAMP
 }
 
 struct DecodeState {
-    unsigned* bar = nullptr;              // [0] counter, [1] error flag (device)
+    unsigned* bar = nullptr;              // flags[BAR_ERR + 512] (device)
+    uint16_t* ws = nullptr;               // per-layer activation scratch (MAXL layers)
     int grid = 0;
 };
 std::mutex g_dec_mu;
@@ -468,14 +530,14 @@ int32_t launch_decode(const d3d_phi3_decode_args* a, DecodeState* st) {
         cus = prop.multiProcessorCount;
     });
     D3D_HIP(attr_err);
-    if (per_cu < 1 || cus < 1) {
+    if (per_cu < 1 || cus < 1 || cus > BAR_ERR) {
         d3d_set_error_("d3d_phi3_decode_token: the persistent decode kernel does not fit on a CU");
         return D3D_EHIP;
     }
     DecP p;
     p.n_layers = a->n_layers, p.rows = a->rows, p.heads = a->heads, p.vocab = a->vocab, p.t_new = a->t_new, p.t_max = a->t_max;
     p.eps = a->rms_eps, p.scale = 1.0f / sqrtf((float)a->head_dim);
-    p.x = (uint16_t*)a->x, p.qkv = (uint16_t*)a->qkv, p.attn = (uint16_t*)a->attn, p.act = (uint16_t*)a->act, p.logits = (uint16_t*)a->logits;
+    p.x = (uint16_t*)a->x, p.logits = (uint16_t*)a->logits, p.ws = st->ws;
     for (int l = 0; l < a->n_layers; ++l) {
         p.qkv_w[l] = (const uint16_t*)a->qkv_w[l], p.o_w[l] = (const uint16_t*)a->o_w[l], p.gu_w[l] = (const uint16_t*)a->gate_up_w[l];
         p.down_w[l] = (const uint16_t*)a->down_w[l], p.n1[l] = a->n1[l], p.n2[l] = a->n2[l], p.prompt_qkv[l] = (const uint16_t*)a->prompt_qkv[l];
@@ -487,7 +549,7 @@ int32_t launch_decode(const d3d_phi3_decode_args* a, DecodeState* st) {
         const char* e = getenv("D3D_DECODE_DEBUG");
         p.debug = e ? atoi(e) : 0;
     }
-    D3D_HIP(hipMemsetAsync(st->bar, 0, sizeof(unsigned), s));                      // the arrival counter; the error flag is sticky
+    D3D_HIP(hipMemsetAsync(st->bar, 0, BAR_ERR * sizeof(unsigned), s));            // the arrival epochs; the error flag is sticky
     void* args[] = {&p};
     D3D_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3(cus * (per_cu > 1 ? 1 : per_cu)), dim3(DT), args, sh, s));
     return D3D_OK;
@@ -512,11 +574,26 @@ int32_t d3d_phi3_decode_token_persistent(const d3d_phi3_decode_args* a) {
         std::lock_guard<std::mutex> lock(g_dec_mu);
         st = &g_dec_states[(hipStream_t)a->stream];
         if (!st->bar) {
-            D3D_HIP(hipMalloc(&st->bar, 2 * sizeof(unsigned)));
-            D3D_HIP(hipMemset(st->bar, 0, 2 * sizeof(unsigned)));
+            D3D_HIP(hipMalloc(&st->bar, (BAR_ERR + 512) * sizeof(unsigned)));
+            D3D_HIP(hipMemset(st->bar, 0, (BAR_ERR + 512) * sizeof(unsigned)));
+            D3D_HIP(hipMalloc(&st->ws, (size_t)MAXL * 8 * (3 * 3072 + 3072 + 8192 + 2 * 3072) * sizeof(uint16_t)));
         }
     }
     return a->dtype == 0 ? launch_decode<true>(a, st) : launch_decode<false>(a, st);
+}
+
+// diagnostics (D3D_DECODE_DEBUG bit 32): the phase stamps of layer 5, workgroups 0 and G-1, in units of 10 ns; 16 values each
+int32_t d3d_phi3_decode_stamps(void* stream, uint64_t* out32) {
+    unsigned* bar = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_dec_mu);
+        auto it = g_dec_states.find((hipStream_t)stream);
+        if (it != g_dec_states.end()) bar = it->second.bar;
+    }
+    if (!bar) return D3D_EINVAL;
+    D3D_HIP(hipStreamSynchronize((hipStream_t)stream));
+    D3D_HIP(hipMemcpy(out32, bar + 1280, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return D3D_OK;
 }
 
 // Blocking check of the stream's sticky error flag (a grid barrier that gave up waiting): call once per generation, after the last token.
@@ -530,9 +607,9 @@ int32_t d3d_phi3_decode_status(void* stream) {
     if (!bar) return D3D_OK;
     unsigned flag = 0;
     D3D_HIP(hipStreamSynchronize((hipStream_t)stream));
-    D3D_HIP(hipMemcpy(&flag, bar + 1, sizeof(flag), hipMemcpyDeviceToHost));
+    D3D_HIP(hipMemcpy(&flag, bar + BAR_ERR, sizeof(flag), hipMemcpyDeviceToHost));
     if (flag) {
-        D3D_HIP(hipMemset(bar + 1, 0, sizeof(unsigned)));
+        D3D_HIP(hipMemset(bar + BAR_ERR, 0, sizeof(unsigned)));
         d3d_set_error_("d3d_phi3_decode_token: a grid barrier of the persistent decode kernel timed out (the token's logits are invalid)");
         return D3D_EHIP;
     }
