@@ -262,11 +262,16 @@ def test_flash_attention_packed_ragged(hd, dt, tol, causal, v_tr, monkeypatch):
     assert float(out[T:].abs().max()) == 0.0                     # padding rows untouched
 
 
+@pytest.mark.parametrize("split", [None, "2"])
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 6e-3), (torch.float16, 1e-3)])
-def test_decode_attention_kv_cache(hd, dt, tol):
-    """d3d_decode_attention: one query per sequence over [prompt keys read in place from a packed QKV buffer | side cache | the
+def test_decode_attention_kv_cache(hd, dt, tol, split, monkeypatch):
+    """(split = D3D_DECODE_SPLIT: the keys of a (sequence, head) cut into ranges whose partial softmax results the last workgroup
+    to finish merges -- off by default, kept as a tested knob.)
+    d3d_decode_attention: one query per sequence over [prompt keys read in place from a packed QKV buffer | side cache | the
     current token], ragged prompts, several decode steps; vs fp32 softmax attention over the same (16-bit) keys and values.  The
     fused-RoPE form (un-rotated q, k + cos/sin/pos) must give what rope_inplace followed by the plain form gives."""
+    if split is not None:
+        monkeypatch.setenv("D3D_DECODE_SPLIT", split)
     torch.manual_seed(6)
     H, d, Tmax = 4, 96, 5
     lens = [1, 63, 300, 129]
