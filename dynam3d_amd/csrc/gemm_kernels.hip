@@ -672,10 +672,15 @@ int32_t launch(const void* A, const void* W, void* C, const void* bias, const vo
 // the row-statistics prologue cost 13-31 us per projection against 9 us for the separate norm launch; dropped.)
 // ================================================================================================
 // HALF: 16 instead of 32 columns per workgroup (twice as many workgroups: the narrow o_proj / down_proj then cover 192 CUs, not 96)
-template <bool BF16, int EPI, bool HALF>
+// NORM: X is the RAW residual stream and the kernel applies HF Phi3RMSNorm (gain `nw`, float32) to it on the fly -- every workgroup
+// recomputes the <= 16 row statistics (wave per row, the lane / chunk order of k_norm: bit-identical to d3d_norm) while its first
+// weight fragments are in flight, and normalises the activation fragments as it loads them.  Saves the d3d_norm launch in front of
+// the qkv / gate_up / lm_head projections of a decode token (64 + 1 launches of ~7 us each per token).
+template <bool BF16, int EPI, bool HALF, bool NORM = false>
 __global__ void __launch_bounds__(1024)
 k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
-              const uint16_t* __restrict__ residual, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldc) {
+              const uint16_t* __restrict__ residual, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldc,
+              const float* __restrict__ nw = nullptr, float eps = 0.f) {
     extern __shared__ __attribute__((aligned(16))) float sk_lds[];      // [NW][2][64] float4
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
     const int fi = lane & 15, fg = lane >> 4;
@@ -697,7 +702,45 @@ k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, ui
         }
     }
     const uint16_t* xr = X + (int64_t)(fi < M ? fi : M - 1) * ldx + fg * 8;      // rows >= M: a duplicate, never stored
-    auto xfrag = [&](int stp) -> uint4 { return *reinterpret_cast<const uint4*>(xr + stp * 32); };
+    float rstd = 1.f;
+    if constexpr (NORM) {
+        float* rs = sk_lds + NW * 2 * 64 * 4;                                    // [16] behind the reduction buffer
+        for (int r = wave; r < M; r += NW) {
+            const uint16_t* row = X + (int64_t)r * ldx;
+            float ss = 0.f;
+            for (int c = 0; c < K / 512; ++c) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(row + c * 512 + lane * 8);
+                const uint16_t* h = reinterpret_cast<const uint16_t*>(&raw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = to_f32<BF16>(h[j]);
+                    ss += v * v;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+            if (lane == 0) rs[r] = rsqrtf(ss / (float)K + eps);
+        }
+        __syncthreads();
+        rstd = rs[fi < M ? fi : M - 1];
+    }
+    auto xfrag = [&](int stp) -> uint4 {
+        uint4 raw = *reinterpret_cast<const uint4*>(xr + stp * 32);
+        if constexpr (NORM) {                                                    // weight * x_hat.to(dtype), both products stored 16-bit
+            const float4 w0 = *reinterpret_cast<const float4*>(nw + stp * 32 + fg * 8), w1 = *reinterpret_cast<const float4*>(nw + stp * 32 + fg * 8 + 4);
+            const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            const uint16_t* h = reinterpret_cast<const uint16_t*>(&raw);
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                float a = to_f32<BF16>(h[j]) * rstd, b = to_f32<BF16>(h[j + 1]) * rstd;
+                r16x2<BF16>(a, b);
+                o[j >> 1] = pack2<BF16>(a * ww[j], b * ww[j + 1]);
+            }
+            raw = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        return raw;
+    };
     float4v acc0 = float4v{0.f, 0.f, 0.f, 0.f}, acc1 = float4v{0.f, 0.f, 0.f, 0.f};
     if (first) {
         for (;;) {                                             // software pipeline: batch i+1's weights load under batch i's MFMAs
@@ -754,23 +797,23 @@ k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, ui
     }
 }
 
-template <bool BF16, int EPI>
+template <bool BF16, int EPI, bool NORM = false>
 int32_t launch_skinny(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
-                      int64_t ldw, int64_t ldc, hipStream_t s) {
+                      int64_t ldw, int64_t ldc, hipStream_t s, const float* nw = nullptr, float eps = 0.f) {
     const int nsteps = K / 32;
     const bool half = EPI != EPI_SWIGLU && N / 32 < 2 * cu_count();   // fewer than two 32-column tiles per CU: 16-column tiles (measured:
                                                                      //   qkv 2.6 -> 3.0 TB/s, down_proj 1.9 -> 2.8 TB/s)
     const int ntiles = half ? N / 16 : N / 32;
-    int nw = ntiles <= 256 ? 16 : (ntiles <= 512 ? 8 : 4);           // ~2000-4000 waves on the chip, K / 32 / nw steps each
-    while (nw > 1 && nsteps / nw < 2) nw >>= 1;
-    const size_t sh = (size_t)nw * 2 * 64 * 16;
+    int nwv = ntiles <= 256 ? 16 : (ntiles <= 512 ? 8 : 4);           // ~2000-4000 waves on the chip, K / 32 / nw steps each
+    while (nwv > 1 && nsteps / nwv < 2) nwv >>= 1;
+    const size_t sh = (size_t)nwv * 2 * 64 * 16 + 64;
     if (half) {
         if constexpr (EPI != EPI_SWIGLU)
-            hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, true>), dim3(ntiles), dim3(nw * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,
-                               (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc);
+            hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, true, NORM>), dim3(ntiles), dim3(nwv * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,
+                               (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, nw, eps);
     } else {
-        hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, false>), dim3(ntiles), dim3(nw * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,
-                           (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc);
+        hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, false, NORM>), dim3(ntiles), dim3(nwv * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,
+                           (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, nw, eps);
     }
     D3D_LAUNCH_CHECK();
 }
@@ -806,6 +849,22 @@ extern "C" {
 // 16-byte aligned rows (lda, ldw multiples of 8).  M is arbitrary (edge tiles are masked).
 int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias, const void* residual, int32_t M, int32_t N, int32_t K,
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream);
+
+// RMSNorm (HF Phi3RMSNorm, float32 gain) fused into the weight-streaming GEMM of <= 16 rows: C = epi(RMSNorm(A) W^T), epilogue 0 or 6.
+int32_t d3d_gemm_nt_rmsnorm(const void* A, const float* norm_w, float eps, const void* W, void* C, int32_t M, int32_t N, int32_t K, int64_t lda,
+                            int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, void* stream) {
+    if (M <= 0) return D3D_OK;
+    if (M > 16 || N % 32 != 0 || K % 512 != 0 || (lda & 7) || (ldw & 7) || (ldc & 3) || !norm_w || (epilogue != EPI_NONE && epilogue != EPI_SWIGLU)) {
+        d3d_set_error_("d3d_gemm_nt_rmsnorm: needs M <= 16, N % 32 == 0, K % 512 == 0, lda/ldw % 8 == 0, ldc % 4 == 0, epilogue 0 or 6");
+        return D3D_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (epilogue == EPI_NONE)
+        return dtype == 0 ? launch_skinny<true, EPI_NONE, true>(A, W, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, s, norm_w, eps)
+                          : launch_skinny<false, EPI_NONE, true>(A, W, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, s, norm_w, eps);
+    return dtype == 0 ? launch_skinny<true, EPI_SWIGLU, true>(A, W, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, s, norm_w, eps)
+                      : launch_skinny<false, EPI_SWIGLU, true>(A, W, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, s, norm_w, eps);
+}
 
 int32_t d3d_gemm_reserve_workspace(void* stream) {
     SplitWorkspace* w = nullptr;

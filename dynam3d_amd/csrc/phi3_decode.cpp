@@ -4,6 +4,7 @@
 // allocation, ~15 us each) left the GPU idle most of the time.  Reference: the decoder layers under
 // `llava.generate(..., do_sample=False)` (VLN-POL:463; HF Phi3DecoderLayer with use_cache).
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/dynam3d_hip.h"
 
@@ -21,6 +22,11 @@ extern "C" int32_t d3d_phi3_decode_token(const d3d_phi3_decode_args* a) {
         return D3D_EINVAL;
     }
     if (d3d_phi3_decode_persistent_ok(a)) return d3d_phi3_decode_token_persistent(a);      // (D3D_DECODE_PERSISTENT=0: the launch-per-op path below)
+    // D3D_DECODE_FUSE_NORM=1: RMSNorm inside the projection that follows it (d3d_gemm_nt_rmsnorm: 5 launches per layer instead of 7).
+    // Bit-identical, but SLOWER -- 3.76 against 3.46 ms per token (tools/bench_decode.py): every workgroup of the GEMM re-reads the 8 rows
+    // and normalises its fragments in the loop that should only be waiting for weights, which costs more than the 7 us launch it saves.
+    const char* fe = getenv("D3D_DECODE_FUSE_NORM");
+    const bool fuse = fe && fe[0] == '1' && Hd % 512 == 0 && qkv_w % 32 == 0 && (2 * I) % 32 == 0;
     void* s = a->stream;
     void* x = a->x;                       // (rows, hidden) in / out: the residual stream
     int32_t rc;
@@ -30,18 +36,30 @@ extern "C" int32_t d3d_phi3_decode_token(const d3d_phi3_decode_args* a) {
         if (rc != D3D_OK) return rc; \
     } while (0)
     for (int32_t l = 0; l < a->n_layers; ++l) {
-        D3D_TRY(d3d_norm(x, a->n1[l], nullptr, a->h, B, Hd, Hd, Hd, a->rms_eps, 1, dt, s));
-        D3D_TRY(d3d_gemm_nt(a->h, a->qkv_w[l], a->qkv, nullptr, nullptr, B, (int32_t)qkv_w, Hd, Hd, Hd, qkv_w, dt, 0, s));
+        if (fuse) {
+            D3D_TRY(d3d_gemm_nt_rmsnorm(x, a->n1[l], a->rms_eps, a->qkv_w[l], a->qkv, B, (int32_t)qkv_w, Hd, Hd, Hd, qkv_w, dt, 0, s));   // RMSNorm inside
+        } else {
+            D3D_TRY(d3d_norm(x, a->n1[l], nullptr, a->h, B, Hd, Hd, Hd, a->rms_eps, 1, dt, s));
+            D3D_TRY(d3d_gemm_nt(a->h, a->qkv_w[l], a->qkv, nullptr, nullptr, B, (int32_t)qkv_w, Hd, Hd, Hd, qkv_w, dt, 0, s));
+        }
         D3D_TRY(d3d_decode_attention(a->qkv, a->prompt_qkv[l], a->cu_seqlens, (char*)a->knew + (int64_t)l * a->cache_layer_stride_bytes,
                                      (char*)a->vnew + (int64_t)l * a->cache_layer_stride_bytes, a->attn, B, H, hd, a->t_new, a->t_max,
                                      a->max_prompt_len, a->cos_t, a->sin_t, a->pos, dt, s));                      // RoPE of q, k inside
         D3D_TRY(d3d_gemm_nt(a->attn, a->o_w[l], x, nullptr, x, B, Hd, Hd, Hd, Hd, Hd, dt, 4, s));                 // + residual, in place
-        D3D_TRY(d3d_norm(x, a->n2[l], nullptr, a->h, B, Hd, Hd, Hd, a->rms_eps, 1, dt, s));
-        D3D_TRY(d3d_gemm_nt(a->h, a->gate_up_w[l], a->act, nullptr, nullptr, B, 2 * I, Hd, Hd, Hd, I, dt, 6, s));  // SwiGLU (interleaved rows)
+        if (fuse) {
+            D3D_TRY(d3d_gemm_nt_rmsnorm(x, a->n2[l], a->rms_eps, a->gate_up_w[l], a->act, B, 2 * I, Hd, Hd, Hd, I, dt, 6, s));            // + SwiGLU
+        } else {
+            D3D_TRY(d3d_norm(x, a->n2[l], nullptr, a->h, B, Hd, Hd, Hd, a->rms_eps, 1, dt, s));
+            D3D_TRY(d3d_gemm_nt(a->h, a->gate_up_w[l], a->act, nullptr, nullptr, B, 2 * I, Hd, Hd, Hd, I, dt, 6, s));  // SwiGLU (interleaved rows)
+        }
         D3D_TRY(d3d_gemm_nt(a->act, a->down_w[l], x, nullptr, x, B, Hd, I, I, I, Hd, dt, 4, s));                   // + residual, in place
     }
-    D3D_TRY(d3d_norm(x, a->norm_w, nullptr, a->h, B, Hd, Hd, Hd, a->rms_eps, 1, dt, s));
-    D3D_TRY(d3d_gemm_nt(a->h, a->lm_head_w, a->logits, nullptr, nullptr, B, a->vocab, Hd, Hd, Hd, a->vocab, dt, 0, s));
+    if (fuse && a->vocab % 32 == 0) {
+        D3D_TRY(d3d_gemm_nt_rmsnorm(x, a->norm_w, a->rms_eps, a->lm_head_w, a->logits, B, a->vocab, Hd, Hd, Hd, a->vocab, dt, 0, s));
+    } else {
+        D3D_TRY(d3d_norm(x, a->norm_w, nullptr, a->h, B, Hd, Hd, Hd, a->rms_eps, 1, dt, s));
+        D3D_TRY(d3d_gemm_nt(a->h, a->lm_head_w, a->logits, nullptr, nullptr, B, a->vocab, Hd, Hd, Hd, a->vocab, dt, 0, s));
+    }
 #undef D3D_TRY
     return D3D_OK;
 }

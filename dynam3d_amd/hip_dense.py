@@ -12,6 +12,7 @@ from ._lib import f32, i32, i64, vp
 EPI = dict(none=0, bias=1, bias_quick_gelu=2, bias_gelu=3, res=4, bias_res=5, swiglu=6, lrelu=7, lrelu_bwd=8)
 
 _lib.register("d3d_gemm_nt", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, vp])
+_lib.register("d3d_gemm_nt_rmsnorm", [vp, vp, f32, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, vp])
 _lib.register("d3d_gemm_nt_tile", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32, vp])
 _lib.register("d3d_gemm_reserve_workspace", [vp])
 _lib.register("d3d_norm", [vp, vp, vp, vp, i32, i32, i64, i64, f32, i32, i32, vp])
@@ -114,6 +115,15 @@ class HipDense:
 
     def linear_swiglu(self, x, w_interleaved):
         return self.gemm(x, w_interleaved, None, None, "swiglu")
+
+    def linear_rmsnorm(self, x, norm_w, eps, w, swiglu=False):
+        """epilogue(RMSNorm(x) w^T) for <= 16 rows, the norm applied inside the weight-streaming GEMM (d3d_gemm_nt_rmsnorm)."""
+        M, K = x.shape
+        N = w.shape[0]
+        out = torch.empty((M, N // 2 if swiglu else N), dtype=x.dtype, device=x.device)
+        _lib.check(self.lib.d3d_gemm_nt_rmsnorm(_p(x), _p(norm_w), float(eps), _p(w), _p(out), M, N, K, x.stride(0), w.stride(0), out.stride(0),
+                                                0 if x.dtype == torch.bfloat16 else 1, 6 if swiglu else 0, self._stream()))
+        return out
 
     # ---- row kernels (csrc/dense_kernels.hip) -------------------------------------------------------------
     @staticmethod

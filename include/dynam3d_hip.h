@@ -295,6 +295,11 @@ typedef struct d3d_phi3_decode_args {
     void* stream;
 } d3d_phi3_decode_args;
 int32_t d3d_phi3_decode_token(const d3d_phi3_decode_args* args);
+/* C = epilogue(RMSNorm(A) W^T) for <= 16 rows (decode): HF Phi3RMSNorm with the float32 gain `norm_w` applied to the raw residual stream
+ * inside the weight-streaming GEMM (every workgroup recomputes the row statistics under its first weight loads; bit-identical to
+ * d3d_norm followed by d3d_gemm_nt).  epilogue 0 (none) or 6 (SwiGLU over interleaved gate/up rows).  K % 512 == 0, N % 32 == 0. */
+int32_t d3d_gemm_nt_rmsnorm(const void* A_d, const float* norm_w_d, float eps, const void* W_d, void* C_d, int32_t M, int32_t N, int32_t K,
+                            int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, void* stream);
 /* llava-phi-3-mini's decoder (hidden 3072, mlp 8192, head_dim 96) at <= 8 rows runs as ONE cooperative launch per token (persistent
  * workgroups, grid barriers between the phases: csrc/decode_kernels.hip; D3D_DECODE_PERSISTENT=0 keeps the launch-per-op path).  A
  * grid barrier that times out raises a sticky per-stream flag instead of hanging the device; d3d_phi3_decode_status synchronises the

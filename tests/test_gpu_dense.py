@@ -152,6 +152,23 @@ def test_gemm_skinny_decode_rows(hd, dt, tol):
         assert torch.equal(hd.linear(x, w, None, None, r), hd.linear(x, w, None, None, r))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gemm_skinny_fused_rmsnorm(hd, dt):
+    """d3d_gemm_nt_rmsnorm (decode: RMSNorm applied to the raw residual stream inside the weight-streaming GEMM) is BIT-identical to
+    d3d_norm followed by d3d_gemm_nt: plain and SwiGLU epilogues, 1 / 8 / 16 rows, the Phi-3 decode shapes."""
+    from dynam3d_amd.hip_dense import interleave_gate_up
+    torch.manual_seed(9)
+    for M, N, K in ((8, 9216, 3072), (1, 3072, 3072), (16, 16384, 1024), (8, 32064, 3072), (5, 96, 512)):
+        x = (torch.randn(M, K, device="cuda") * 1.7 + 0.2).to(dt)
+        g = (torch.randn(K, device="cuda") * 0.2 + 1).float()
+        w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
+        h = hd.rms_norm(x, g, 1e-5)
+        assert torch.equal(hd.linear_rmsnorm(x, g, 1e-5, w), hd.linear(h, w, None, None)), (M, N, K)
+        if (N // 2) % 16 == 0:
+            wi = interleave_gate_up(w)
+            assert torch.equal(hd.linear_rmsnorm(x, g, 1e-5, wi, swiglu=True), hd.linear_swiglu(h, wi)), (M, N, K, "swiglu")
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1e-3), (torch.float16, 2e-4)])
 def test_norms_rope_swiglu(hd, dt, tol):
     torch.manual_seed(2)
