@@ -247,6 +247,7 @@ class Phi3Decoder:
         self.lm_head_w = t(sd["language_model.lm_head.weight"])
         self._rope_cache = {}
 
+    PRUNE_LAST_LAYER = True            # prefill_logits_packed: the last layer's o_proj / MLP on the B last rows only
     MAX_DECODE_ROWS = 16          # k_gemm_skinny: M <= 16
     MAX_DECODE_KEYS = 4096 + 64   # k_decode_attn keeps one score per key in LDS
     SLIDING_WINDOW = 2047         # Phi-3-mini-4k-instruct config.json: every layer attends to the last 2047 keys only
@@ -318,21 +319,28 @@ class Phi3Decoder:
         max_len = max(lens)
         cos, sin = self._rope(max_len)
         Ht = c.heads + 2 * c.kv_heads
-        for L in self.layers:
+        last_rows = (cu[1:] - 1).long()
+        for li, L in enumerate(self.layers):
             h = D.rms_norm(x, L["n1"], c.rms_eps)
             qkv = D.linear(h, L["qkv_w"], None)
             D.rope_packed_(qkv, c.heads + c.kv_heads, c.head_dim, cos, sin, pos)
             if keep_kv is not None:
                 keep_kv.append(qkv)
             a = D.attention_packed(qkv.view(Tp, Ht, c.head_dim), c.heads, True, cu, B, max_len, n_valid=cu_h[-1])
-            x = D.linear(a.view(Tp, c.heads * c.head_dim), L["o_w"], None, residual=x)
+            a = a.view(Tp, c.heads * c.head_dim)
+            if li == len(self.layers) - 1 and self.PRUNE_LAST_LAYER:
+                # Behind the last layer's attention every operation is row-wise and only each prompt's LAST row is read (the logits of the
+                # next token; the layer's keys / values -- all rows -- are already in `qkv`): o_proj, the MLP, the final norm and the
+                # lm_head run on B rows instead of Tp.  Same arithmetic per row, 1/32 of the stack's o_proj + MLP GEMM time saved.
+                a, x = a[last_rows].contiguous(), x[last_rows].contiguous()
+            x = D.linear(a, L["o_w"], None, residual=x)
             h = D.rms_norm(x, L["n2"], c.rms_eps)
             with TIMER.range("phi3.gate_up_proj"):
                 act = D.linear_swiglu(h, L["gu_w"], self.interleave_gu)
             x = D.linear(act, L["down_w"], None, residual=x)
         self.last_packed_rows = Tp
         self._last_cu = cu
-        last = x[(cu[1:] - 1).long()]
+        last = x if x.shape[0] == B else x[last_rows]
         last = D.rms_norm(last, self.norm_w, c.rms_eps)
         return D.linear(last, self.lm_head_w, None).float()
 
