@@ -27,7 +27,7 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2
 PEAK_HBM_GBS = 8000.0
 
 
-def step_flops(cfg, lengths, n_img):
+def step_flops(cfg, lengths, n_img, pruned_last_layer=False):
     """Algorithmic FLOPs of one batch step (BASELINE.md section 3 formula, evaluated exactly for the configs and
     the real (unpadded, causal) sequence lengths)."""
     v, l = cfg.vit, cfg.llm
@@ -36,8 +36,14 @@ def step_flops(cfg, lengths, n_img):
     embed = 2 * (L - 1) * 3 * v.patch * v.patch * W
     clip = v.layers * layer + embed + 2 * L * W * v.out_dim
     llava = (v.layers - 1) * layer + embed + 2 * (L - 1) * (W * v.proj_dim + v.proj_dim * v.proj_dim)
-    per_tok = 2 * (l.hidden * (l.heads + 2 * l.kv_heads) * l.head_dim + l.heads * l.head_dim * l.hidden + 3 * l.hidden * l.mlp)
-    phi = sum(l.layers * (per_tok * S + 2 * S * S * l.heads * l.head_dim) + 2 * l.hidden * l.vocab for S in lengths)
+    qkv_tok = 2 * l.hidden * (l.heads + 2 * l.kv_heads) * l.head_dim
+    tail_tok = 2 * (l.heads * l.head_dim * l.hidden + 3 * l.hidden * l.mlp)          # o_proj + MLP: row-wise, behind the attention
+    per_tok = qkv_tok + tail_tok
+    # the product evaluates the LAST layer's o_proj / MLP on each prompt's last row only (towers.py PRUNE_LAST_LAYER: only that row's
+    # logits are read and everything behind the attention is row-wise) -- counted as executed, not as the reference executes it
+    last_tail_rows = (lambda S: 1) if pruned_last_layer else (lambda S: S)
+    phi = sum((l.layers - 1) * per_tok * S + qkv_tok * S + tail_tok * last_tail_rows(S) + l.layers * 2 * S * S * l.heads * l.head_dim
+              + 2 * l.hidden * l.vocab for S in lengths)
     tok3d = n_img * 17e9        # SURVEY 8a row a7 (2-layer set encoder over 576+n tokens), informational
     return dict(clip=n_img * clip, llava=n_img * llava, phi3=phi, tokens3d=tok3d, total=n_img * (clip + llava) + phi + tok3d)
 
@@ -202,7 +208,7 @@ def main():
 
     if rank == 0:
         ms = dt / a.steps * 1e3
-        fl = step_flops(cfg, lengths_seen[-1], B)
+        fl = step_flops(cfg, lengths_seen[-1], B, pruned_last_layer=bool(getattr(net.llm, "PRUNE_LAST_LAYER", False)))
         rows_gemm = getattr(net.llm, "last_packed_rows", None) or B * max(lengths_seen[-1])   # rows the GEMM actually processes
         tsum = TIMER.summary()
         n_gu, ms_gu = tsum.get("phi3.gate_up_proj", (0, float("nan")))
