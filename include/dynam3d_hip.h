@@ -223,8 +223,12 @@ int32_t d3d_gemm_nt(const void* A_d, const void* W_d, void* C_d, const void* bia
  * stepping K-halves / whole K tiles, 258 = 257 with the partial last round of tiles split along K: the K-slices write fp32
  * partials to a library-owned per-stream workspace and a second launch on the same stream sums them in slice order
  * (deterministic) and runs the epilogue -- no workgroup waits for another one, any number of streams / processes may share
- * the GPU.  259 = experiment (LDS-DMA of W issued between the MFMAs).  d3d_gemm_nt picks a tile (and splits the M remainder)
- * itself.  epilogue 7 = LeakyReLU(0.01) for the tcnn CutlassMLP replacement; 8 = its backward factor (see d3d_lrelu_bwd below). */
+ * the GPU.  260 / 264 = 257 / 258 with the INTERLEAVED K loop (both waves of a SIMD run one software-pipelined stream: the
+ * ds_read_b128 of the next K-half one behind every ~3rd MFMA, one barrier per K tile) -- what d3d_gemm_nt uses (D3D_GEMM_LOOP=0:
+ * 257 / 258).  All 256-tile variants store through an LDS transposition (16-byte row-contiguous stores): they need ldc % 8 == 0 and
+ * 16-byte aligned C / residual.  259 = experiment (LDS-DMA of W issued between the MFMAs); 261-263 = timing experiments with WRONG
+ * results (cache-hot operands / no loads in the K loop / no epilogue); 301-303 = 257 / 260 / 262 with in-kernel cycle stamps printed
+ * on stderr (bf16, epilogue 0 only).  d3d_gemm_nt picks a tile (and splits the M remainder) itself.  epilogue 7 = LeakyReLU(0.01) for the tcnn CutlassMLP replacement; 8 = its backward factor (see d3d_lrelu_bwd below). */
 int32_t d3d_gemm_nt_tile(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
                          int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
                          int32_t tile, void* stream);
