@@ -338,6 +338,8 @@ class Phi3Decoder:
             if h.shape[0] == Tp:
                 with TIMER.range("phi3.gate_up_proj"):                      # (bench.py's roofline launch: the full-row GEMMs only)
                     act = D.linear_swiglu(h, L["gu_w"], self.interleave_gu)
+                with TIMER.range("phi3.event_pair_overhead"):               # an EMPTY bracket right behind it: what two event records
+                    pass                                                    # cost on this stream at this point (bench.py subtracts it)
             else:
                 act = D.linear_swiglu(h, L["gu_w"], self.interleave_gu)
             x = D.linear(act, L["down_w"], None, residual=x)
