@@ -38,6 +38,49 @@ constexpr int NTHREADS = 256;
 
 #include "gemm_epilogue.h"
 
+// Transposed epilogue of one wave's NI*16 x 64 sub-tile (256-tile kernel: NI = 8, 128-tile kernel: NI = 4).  In the accumulator layout a
+// lane owns 4 neighbouring columns of one row, so a direct store instruction touches 16 rows x 32 B: ~8200 shader cycles per 256 x 256
+// tile (cycle stamps, profiles/r02_gemm_cycle_stamps.txt: the same with ONE workgroup on the chip -- it is the CU's own store path, not
+// the fabric).  Instead the wave packs its sub-tile to 16 bit, parks it in `reg` -- its own NI * 2 KiB of the (now idle) K-tile
+// buffers: ds_write_b64, 16-byte chunks XOR-swizzled by row -- and reads it back row-major: ds_read_b128 + global_store_dwordx4,
+// 8 rows x 128 B per instruction (SwiGLU: 16 rows x 64 B).  The residual is added on the way out, loaded with the same
+// row-contiguous 16-byte pattern (same rounding points).  Needs ldc % 8 == 0 and 16-byte aligned C / residual; every wave of the
+// workgroup must have passed a barrier behind its last read of the K-tile buffers.
+template <bool BF16, int EPI, int NI>
+__device__ __forceinline__ void epilogue_transposed(const float4v (&acc)[NI][4], char* reg, int lane, int row_base /* first row of the
+                                                    sub-tile */, int col_base /* first (input) column of the sub-tile */, int M,
+                                                    uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
+                                                    const uint16_t* __restrict__ residual, int64_t ldc) {
+    const int fi = lane & 15, fg = lane >> 4;
+    constexpr int RB = EPI == EPI_SWIGLU ? 64 : 128;     // bytes per sub-tile row
+    constexpr int LPR = RB / 16, RPP = 64 / LPR;         // lanes per row, rows per read-back pass
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = i * 16 + fi;
+        const int m = row_base + row;
+#pragma unroll
+        for (int j = 0; j < 4; j += (EPI == EPI_SWIGLU ? 2 : 1)) {
+            const uint2 o = epi_pack<BF16, EPI, true>(acc[i][j], acc[i][EPI == EPI_SWIGLU ? j + 1 : j], bias, residual, m, col_base + j * 16, fg, ldc);
+            const int cb = (EPI == EPI_SWIGLU ? j * 8 + fg * 4 : j * 16 + fg * 4) * 2;          // byte offset in the row
+            *reinterpret_cast<uint2*>(reg + row * RB + ((((cb >> 4) ^ row) & (LPR - 1)) << 4) + (cb & 15)) = o;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS operations execute in order: its own writes are visible to its reads
+    const int ocol = (EPI == EPI_SWIGLU ? col_base / 2 : col_base) + (lane % LPR) * 8;
+#pragma unroll
+    for (int p = 0; p < NI * 16 / RPP; ++p) {
+        const int row = p * RPP + lane / LPR;
+        const int m = row_base + row;
+        uint4 v = *reinterpret_cast<const uint4*>(reg + row * RB + ((((lane % LPR) ^ row) & (LPR - 1)) << 4));
+        if (m >= M) continue;
+        if constexpr (EPI == EPI_RES || EPI == EPI_BIAS_RES) {
+            const uint4 r = *reinterpret_cast<const uint4*>(residual + (int64_t)m * ldc + ocol);
+            v.x = add2_16<BF16>(v.x, r.x), v.y = add2_16<BF16>(v.y, r.y), v.z = add2_16<BF16>(v.z, r.z), v.w = add2_16<BF16>(v.w, r.w);
+        }
+        *reinterpret_cast<uint4*>(C + (int64_t)m * ldc + ocol) = v;
+    }
+}
+
 // NSTAGE = LDS K-tile ring depth.  2 (64 KiB, two workgroups per CU) is the throughput configuration; 4 (128 KiB, one
 // workgroup per CU) keeps three K tiles in flight for grids that cannot give every CU two workgroups anyway (the ViT
 // projections at M = 2056: 136 tiles) -- there a K step is bounded by the LDS-DMA latency, not by its 32 MFMAs.
@@ -45,7 +88,7 @@ template <bool BF16, int EPI, int NSTAGE>
 __global__ void __launch_bounds__(NTHREADS, 2)
 k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* __restrict__ C,
           const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, int M, int N, int K, int64_t lda,
-          int64_t ldw, int64_t ldc, int tiles_m, int tiles_n) {
+          int64_t ldw, int64_t ldc, int tiles_m, int tiles_n, int wide_stores /* ldc % 8 == 0, 16-byte aligned C / residual */) {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2][A 128x64 | B 128x64]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- XCD-aware tile mapping (bijective for any grid size) ------------------------------------------
@@ -123,6 +166,14 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
     }
 
     // ---- epilogue: lane holds, for tile (i,j): row m = row0+wr*64+i*16+fi, cols n = col0+wc*64+j*16+fg*4 .. +3
+    if constexpr (EPI != EPI_LRELU_BWD) {
+        if (wide_stores) {                                // (workgroup-uniform) through LDS: 16-byte row-contiguous stores, see epilogue_transposed
+            __builtin_amdgcn_s_barrier();                 // every wave is done reading the last K tile
+            epilogue_transposed<BF16, EPI, 4>(acc, reinterpret_cast<char*>(smem) + wave * (64 * (EPI == EPI_SWIGLU ? 64 : 128)), lane,
+                                              row0 + wr * 64, col0 + wc * 64, M, C, bias, residual, ldc);
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = row0 + wr * 64 + i * 16 + fi;
@@ -420,41 +471,9 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
             for (int j = 0; j < 4; ++j) store4<BF16, EPI>(acc[i][j], acc[i][j], C, bias, residual, m, col0 + wn * 64 + j * 16, fg, ldc);
         }
     } else {
-        // Transposed epilogue.  In the accumulator layout a lane owns 4 neighbouring columns of one row, so a direct store instruction
-        // touches 16 rows x 32 B: 32 instructions per wave, ~8200 shader cycles per tile (cycle stamps, profiles/r02_gemm_cycle_stamps.txt:
-        // the same with ONE workgroup on the chip -- it is the CU's own store path, not the fabric).  Instead every wave packs its
-        // 128 x 64 sub-tile to 16 bit, parks it in its own 16 KiB of the (now idle) K-tile buffers -- ds_write_b64, 16-byte chunks
-        // XOR-swizzled by row -- and reads it back row-major: ds_read_b128 + global_store_dwordx4, 8 rows x 128 B per instruction
-        // (SwiGLU: 16 rows x 64 B).  The residual is added on the way out, loaded with the same row-contiguous 16-byte pattern.
         __builtin_amdgcn_s_barrier();              // every wave is done reading the K-tile buffers
-        constexpr int RB = EPI == EPI_SWIGLU ? 64 : 128;     // bytes per sub-tile row
-        constexpr int LPR = RB / 16, RPP = 64 / LPR;         // lanes per row, rows per read-back pass
-        char* reg = reinterpret_cast<char*>(smem) + wave * (128 * RB);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = i * 16 + fi;
-            const int m = row0 + grp * 128 + row;
-#pragma unroll
-            for (int j = 0; j < 4; j += (EPI == EPI_SWIGLU ? 2 : 1)) {
-                const uint2 o = epi_pack<BF16, EPI, true>(acc[i][j], acc[i][EPI == EPI_SWIGLU ? j + 1 : j], bias, residual, m, col0 + wn * 64 + j * 16, fg, ldc);
-                const int cb = (EPI == EPI_SWIGLU ? j * 8 + fg * 4 : j * 16 + fg * 4) * 2;          // byte offset in the row
-                *reinterpret_cast<uint2*>(reg + row * RB + ((((cb >> 4) ^ row) & (LPR - 1)) << 4) + (cb & 15)) = o;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS operations execute in order: its own writes are visible to its reads
-        const int ocol = (EPI == EPI_SWIGLU ? col0 / 2 + wn * 32 : col0 + wn * 64) + (lane % LPR) * 8;
-#pragma unroll
-        for (int p = 0; p < 128 / RPP; ++p) {
-            const int row = p * RPP + lane / LPR;
-            const int m = row0 + grp * 128 + row;
-            uint4 v = *reinterpret_cast<const uint4*>(reg + row * RB + ((((lane % LPR) ^ row) & (LPR - 1)) << 4));
-            if (m >= M) continue;
-            if constexpr (EPI == EPI_RES || EPI == EPI_BIAS_RES) {
-                const uint4 r = *reinterpret_cast<const uint4*>(residual + (int64_t)m * ldc + ocol);
-                v.x = add2_16<BF16>(v.x, r.x), v.y = add2_16<BF16>(v.y, r.y), v.z = add2_16<BF16>(v.z, r.z), v.w = add2_16<BF16>(v.w, r.w);
-            }
-            *reinterpret_cast<uint4*>(C + (int64_t)m * ldc + ocol) = v;
-        }
+        epilogue_transposed<BF16, EPI, 8>(acc, reinterpret_cast<char*>(smem) + wave * (128 * (EPI == EPI_SWIGLU ? 64 : 128)), lane,
+                                          row0 + grp * 128, col0 + wn * 64, M, C, bias, residual, ldc);
     }
     if constexpr (TIMED) {
         tk[3] = __builtin_readcyclecounter();
@@ -645,7 +664,8 @@ int32_t launch_stages(const void* A, const void* W, void* C, const void* bias, c
     });
     D3D_HIP(attr_err);
     hipLaunchKernelGGL((k_gemm_nt<BF16, EPI, NSTAGE>), dim3(tm * tn), dim3(NTHREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
-                       (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn);
+                       (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn,
+                       (int)((ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (!res || ((uintptr_t)res & 15) == 0)));
     D3D_LAUNCH_CHECK();
 }
 
