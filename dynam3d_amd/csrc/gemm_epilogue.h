@@ -74,6 +74,26 @@ struct TileLanes {
     }
 };
 
+// two pieces per wave instead of four: a 16 * WAVES-row operand tile (the 64-row W tile of the 128 x 64 kernel)
+template <int WAVES>
+__device__ __forceinline__ void stage_tile_dma2(const TileLanes<WAVES>& tl, const uint16_t* __restrict__ base, uint32_t lds_byte_addr, int wave) {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr + (uint32_t)wave * 1024u);
+    uint32_t keep;
+    constexpr int STEP = WAVES * 1024;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "s_add_u32 m0, m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %5\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(tl.off[0]), "v"(tl.off[1]), "s"(dst), "i"(STEP), "s"(base)
+        : "memory");
+}
+
 template <int WAVES>
 __device__ __forceinline__ void stage_tile_dma(const TileLanes<WAVES>& tl, const uint16_t* __restrict__ base, uint32_t lds_byte_addr, int wave) {
     const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr + (uint32_t)wave * 1024u);

@@ -46,20 +46,20 @@ constexpr int NTHREADS = 256;
 // 8 rows x 128 B per instruction (SwiGLU: 16 rows x 64 B).  The residual is added on the way out, loaded with the same
 // row-contiguous 16-byte pattern (same rounding points).  Needs ldc % 8 == 0 and 16-byte aligned C / residual; every wave of the
 // workgroup must have passed a barrier behind its last read of the K-tile buffers.
-template <bool BF16, int EPI, int NI>
-__device__ __forceinline__ void epilogue_transposed(const float4v (&acc)[NI][4], char* reg, int lane, int row_base /* first row of the
+template <bool BF16, int EPI, int NI, int NJ = 4>
+__device__ __forceinline__ void epilogue_transposed(const float4v (&acc)[NI][NJ], char* reg, int lane, int row_base /* first row of the
                                                     sub-tile */, int col_base /* first (input) column of the sub-tile */, int M,
                                                     uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
                                                     const uint16_t* __restrict__ residual, int64_t ldc) {
     const int fi = lane & 15, fg = lane >> 4;
-    constexpr int RB = EPI == EPI_SWIGLU ? 64 : 128;     // bytes per sub-tile row
+    constexpr int RB = (EPI == EPI_SWIGLU ? 16 : 32) * NJ;   // bytes per sub-tile row (NJ 16-column tiles; SwiGLU halves them)
     constexpr int LPR = RB / 16, RPP = 64 / LPR;         // lanes per row, rows per read-back pass
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int row = i * 16 + fi;
         const int m = row_base + row;
 #pragma unroll
-        for (int j = 0; j < 4; j += (EPI == EPI_SWIGLU ? 2 : 1)) {
+        for (int j = 0; j < NJ; j += (EPI == EPI_SWIGLU ? 2 : 1)) {
             const uint2 o = epi_pack<BF16, EPI, true>(acc[i][j], acc[i][EPI == EPI_SWIGLU ? j + 1 : j], bias, residual, m, col_base + j * 16, fg, ldc);
             const int cb = (EPI == EPI_SWIGLU ? j * 8 + fg * 4 : j * 16 + fg * 4) * 2;          // byte offset in the row
             *reinterpret_cast<uint2*>(reg + row * RB + ((((cb >> 4) ^ row) & (LPR - 1)) << 4) + (cb & 15)) = o;
@@ -84,7 +84,10 @@ __device__ __forceinline__ void epilogue_transposed(const float4v (&acc)[NI][4],
 // NSTAGE = LDS K-tile ring depth.  2 (64 KiB, two workgroups per CU) is the throughput configuration; 4 (128 KiB, one
 // workgroup per CU) keeps three K tiles in flight for grids that cannot give every CU two workgroups anyway (the ViT
 // projections at M = 2056: 136 tiles) -- there a K step is bounded by the LDS-DMA latency, not by its 32 MFMAs.
-template <bool BF16, int EPI, int NSTAGE>
+// BNT = tile width: 128 (wave tile 64 x 64, 2 workgroups per CU) or 64 (wave tile 64 x 32, 48 KiB of LDS at two stages -> 3 workgroups per
+// CU, twice as many workgroups: the finer grid for GEMMs whose 128 x 128 grid is a small, badly divisible number of rounds -- the ViT
+// projections at M = 4616).
+template <bool BF16, int EPI, int NSTAGE, int BNT = 128>
 __global__ void __launch_bounds__(NTHREADS, 2)
 k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* __restrict__ C,
           const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, int M, int N, int K, int64_t lda,
@@ -105,14 +108,15 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
     const int gsz = min(GM, tiles_m - gm0);
     const int tm = gm0 + (wg % (GM * tiles_n)) % gsz;
     const int tn = (wg % (GM * tiles_n)) / gsz;
-    const int row0 = tm * BM, col0 = tn * BN;
+    const int row0 = tm * BM, col0 = tn * BNT;
+    constexpr int NJ = BNT / 32;                            // 16-column MFMA tiles per wave: 4 (64 columns) or 2 (32 columns)
 
-    const int wr = wave >> 1, wc = wave & 1;                // wave -> 64x64 sub-tile
-    float4v acc[4][4];
+    const int wr = wave >> 1, wc = wave & 1;                // wave -> 64 x (BNT/2) sub-tile
+    float4v acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
     // LDS: buffer b -> A tile at smem + b*2*BM*BK, B tile right behind it
@@ -122,11 +126,13 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
     tw.init(ldw, col0, N, wave, lane);
     const uint16_t* abase = A + (int64_t)row0 * lda;
     const uint16_t* wbase = W + (int64_t)col0 * ldw;
-    constexpr uint32_t STAGE_BYTES = 2 * BM * BK * 2;                  // A tile + B tile
+    constexpr uint32_t STAGE_BYTES = (BM + BNT) * BK * 2;              // A tile + B tile
+    constexpr int NPIECE = NJ * 2 + 4;                                 // LDS-DMA instructions per wave and K tile: 8 (BNT 128) / 6 (BNT 64)
     auto STAGE = [&](int t) {
         const uint32_t d = lds0 + (uint32_t)(t % NSTAGE) * STAGE_BYTES;
         stage_tile_dma<4>(ta, abase + t * BK, d, wave);
-        stage_tile_dma<4>(tw, wbase + t * BK, d + BM * BK * 2, wave);
+        if constexpr (BNT == 128) stage_tile_dma<4>(tw, wbase + t * BK, d + BM * BK * 2, wave);
+        else stage_tile_dma2<4>(tw, wbase + t * BK, d + BM * BK * 2, wave);
     };
 #pragma unroll
     for (int t = 0; t < NSTAGE - 1; ++t)
@@ -137,30 +143,34 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
         // tile t has landed when at most the (up to NSTAGE-2) younger tiles are still in flight: 8 LDS-DMA per wave and tile
         const int younger = min(t + NSTAGE - 2, nk - 1) - t;
         if (NSTAGE > 3 && younger >= 2) {
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if constexpr (NPIECE == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         } else if (NSTAGE > 2 && younger == 1) {
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if constexpr (NPIECE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                          // tile t visible to all; everyone is done reading tile t-1
         if (t + NSTAGE - 1 < nk) STAGE(t + NSTAGE - 1);         // ... whose buffer the new tile takes
-        const uint16_t* la = smem + (t % NSTAGE) * (2 * BM * BK);
+        const uint16_t* la = smem + (t % NSTAGE) * ((BM + BNT) * BK);
         const uint16_t* lb = la + BM * BK;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            uint4 af[4], bf[4];
+            uint4 af[4], bf[NJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ra = wr * 64 + i * 16 + fi;
                 af[i] = *reinterpret_cast<const uint4*>(la + ra * BK + (((kk * 4 + fg) ^ (ra & 7)) << 3));
-                const int rb = wc * 64 + i * 16 + fi;
-                bf[i] = *reinterpret_cast<const uint4*>(lb + rb * BK + (((kk * 4 + fg) ^ (rb & 7)) << 3));
+                if (i < NJ) {
+                    const int rb = wc * (BNT / 2) + i * 16 + fi;
+                    bf[i] = *reinterpret_cast<const uint4*>(lb + rb * BK + (((kk * 4 + fg) ^ (rb & 7)) << 3));
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<BF16>(bf[j], af[i], acc[i][j]);   // D = C^T tile: rows n, cols m
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16<BF16>(bf[j], af[i], acc[i][j]);   // D = C^T tile: rows n, cols m
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -169,8 +179,8 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
     if constexpr (EPI != EPI_LRELU_BWD) {
         if (wide_stores) {                                // (workgroup-uniform) through LDS: 16-byte row-contiguous stores, see epilogue_transposed
             __builtin_amdgcn_s_barrier();                 // every wave is done reading the last K tile
-            epilogue_transposed<BF16, EPI, 4>(acc, reinterpret_cast<char*>(smem) + wave * (64 * (EPI == EPI_SWIGLU ? 64 : 128)), lane,
-                                              row0 + wr * 64, col0 + wc * 64, M, C, bias, residual, ldc);
+            epilogue_transposed<BF16, EPI, 4, NJ>(acc, reinterpret_cast<char*>(smem) + wave * (64 * (EPI == EPI_SWIGLU ? 16 : 32) * NJ), lane,
+                                                  row0 + wr * 64, col0 + wc * (BNT / 2), M, C, bias, residual, ldc);
             return;
         }
     }
@@ -180,10 +190,10 @@ k_gemm_nt(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16
         if (m >= M) continue;
         if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) store4<BF16, EPI>(acc[i][j], acc[i][j + 1], C, bias, residual, m, col0 + wc * 64 + j * 16, fg, ldc);
+            for (int j = 0; j < NJ; j += 2) store4<BF16, EPI>(acc[i][j], acc[i][j + 1], C, bias, residual, m, col0 + wc * (BNT / 2) + j * 16, fg, ldc);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) store4<BF16, EPI>(acc[i][j], acc[i][j], C, bias, residual, m, col0 + wc * 64 + j * 16, fg, ldc);
+            for (int j = 0; j < NJ; ++j) store4<BF16, EPI>(acc[i][j], acc[i][j], C, bias, residual, m, col0 + wc * (BNT / 2) + j * 16, fg, ldc);
         }
     }
 }
@@ -652,18 +662,18 @@ int32_t launch256_split(const void* A, const void* W, void* C, const void* bias,
     D3D_LAUNCH_CHECK();
 }
 
-template <bool BF16, int EPI, int NSTAGE>
+template <bool BF16, int EPI, int NSTAGE, int BNT = 128>
 int32_t launch_stages(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
                       int64_t ldw, int64_t ldc, hipStream_t s) {
-    const int tm = (M + BM - 1) / BM, tn = N / BN;
-    const size_t sh = (size_t)NSTAGE * 2 * BM * BK * sizeof(uint16_t);
+    const int tm = (M + BM - 1) / BM, tn = N / BNT;
+    const size_t sh = (size_t)NSTAGE * (BM + BNT) * BK * sizeof(uint16_t);
     static std::once_flag attr_once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(attr_once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<BF16, EPI, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<BF16, EPI, NSTAGE, BNT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     });
     D3D_HIP(attr_err);
-    hipLaunchKernelGGL((k_gemm_nt<BF16, EPI, NSTAGE>), dim3(tm * tn), dim3(NTHREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
+    hipLaunchKernelGGL((k_gemm_nt<BF16, EPI, NSTAGE, BNT>), dim3(tm * tn), dim3(NTHREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W, (uint16_t*)C,
                        (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn,
                        (int)((ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (!res || ((uintptr_t)res & 15) == 0)));
     D3D_LAUNCH_CHECK();
@@ -674,6 +684,10 @@ template <bool BF16, int EPI>
 int32_t launch(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
                int64_t ldw, int64_t ldc, hipStream_t s, int stages = 0) {
     const int tiles = ((M + BM - 1) / BM) * (N / BN);
+    if (stages == 64) return launch_stages<BF16, EPI, 2, 64>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s);      // 128 x 64 tiles, 3 workgroups per CU
+    // between one and one and a half workgroups per CU (ViT out-proj / fc2 at M = 4616: 296 tiles for 256 CUs): the 128 x 64 tile doubles
+    // the grid and fits three workgroups per CU -- 22.5 -> 20.3 us (K = 1024), 61.0 -> 57.7 us (K = 4096); larger grids lose with it
+    if (stages == 0 && tiles > cu_count() && tiles * 2 <= cu_count() * 3) return launch_stages<BF16, EPI, 2, 64>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s);
     if (stages == 0) stages = (tiles <= cu_count() && K / BK >= 4) ? 4 : 2;
     return stages == 4 ? launch_stages<BF16, EPI, 4>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s)
                        : launch_stages<BF16, EPI, 2>(A, W, C, bias, res, M, N, K, lda, ldw, ldc, s);
@@ -952,7 +966,7 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream) {
     if (M <= 0) return D3D_OK;
     if (tile == 16) return skinny_dispatch(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, dtype, epilogue, stream);
-    if (tile != 128 && tile != 130 && tile != 132 && (tile < 256 || (tile > 264 && (tile < 301 || tile > 303)))) {
+    if (tile != 128 && tile != 130 && tile != 132 && tile != 164 && (tile < 256 || (tile > 264 && (tile < 301 || tile > 303)))) {
         d3d_set_error_("d3d_gemm_nt_tile: tile must be 128 (130 / 132: 2 / 4 LDS stages forced), 256 (K-half steps), 257 (whole-K-tile steps) or 258 (257 + split-K tail)");
         return D3D_EINVAL;
     }
@@ -991,8 +1005,8 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
         if (tile == 263 && E == EPI_NONE) return launch256<true, EPI_NONE, true, 5>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s); \
         if (tile == 261 && E == EPI_NONE) return launch256<true, EPI_NONE, true, 3>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s); \
         if (tile == 262 && E == EPI_NONE) return launch256<true, EPI_NONE, true, 4>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s); \
-        return dtype == 0 ? launch<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s, tile == 128 ? 0 : tile - 128)  \
-                          : launch<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s, tile == 128 ? 0 : tile - 128);
+        return dtype == 0 ? launch<true, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s, tile == 128 ? 0 : (tile == 164 ? 64 : tile - 128))  \
+                          : launch<false, E>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s, tile == 128 ? 0 : (tile == 164 ? 64 : tile - 128));
     switch (epilogue) {
         D3D_GEMM_CASE(EPI_NONE)
         D3D_GEMM_CASE(EPI_BIAS)

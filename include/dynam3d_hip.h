@@ -219,7 +219,8 @@ int32_t d3d_agent_frame_compact(const float* pool_pos_d, const float* pool_fts_d
 int32_t d3d_gemm_nt(const void* A_d, const void* W_d, void* C_d, const void* bias_d, const void* residual_d, int32_t M,
                     int32_t N, int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue,
                     void* stream);
-/* same with an explicit tile: 128 = 128x128x64 (4 waves, 2 workgroups/CU), 256 / 257 = 256x256x64 staggered wave groups
+/* same with an explicit tile: 128 = 128x128x64 (4 waves, 2 workgroups/CU; 130 / 132: LDS ring depth forced), 164 = 128x64x64 (3 workgroups/CU,
+ * the finer grid for small GEMMs), 256 / 257 = 256x256x64 staggered wave groups
  * stepping K-halves / whole K tiles, 258 = 257 with the partial last round of tiles split along K: the K-slices write fp32
  * partials to a library-owned per-stream workspace and a second launch on the same stream sums them in slice order
  * (deterministic) and runs the epilogue -- no workgroup waits for another one, any number of streams / processes may share

@@ -75,7 +75,7 @@ def test_gemm_epilogues_asymmetric(hd, dt, tol):
         assert rel(hd.linear(big[:, :K], w, None, None).float(), epi_ref("none", big[:, :K].float() @ w.float().t(), None, None, dt)) < tol
 
 
-@pytest.mark.parametrize("tile", [130, 132, 256, 257, 259, 260])
+@pytest.mark.parametrize("tile", [130, 132, 164, 256, 257, 259, 260])
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1e-3), (torch.float16, 2e-4)])
 def test_gemm_forced_tile_kernels(hd, dt, tol, tile):
     """Every kernel variant forced explicitly -- 128x128 with a 2- / 4-deep LDS ring (130 / 132), 256x256x64 staggered in
