@@ -3,8 +3,8 @@
 // Reference: the decoder layers under `llava.generate(..., max_new_tokens=20, do_sample=False)` (VLN-POL:463; HF Phi3DecoderLayer
 // with use_cache).  A decode token is weight streaming: 7.6 GB of bf16 weights + the prompts' keys / values (2.7 GB at 8 x 864
 // prompt rows) against a few MFLOP per byte.  Issued as 7 launches per layer (phi3_decode.cpp) every kernel runs for 8-30 us, of
-// which ~5 us are ramp-up (workgroup dispatch, first bytes' latency) and drain with the HBM pipe empty: 3.7 ms per token for
-// 10.3 GB = 2.8 TB/s.  Here one persistent workgroup per CU (hipLaunchCooperativeKernel: co-residency is guaranteed by the
+// which ~5 us are ramp-up (workgroup dispatch, first bytes' latency) and drain with the HBM pipe empty: 3.45 ms per token for
+// 10.2 GB = 2.95 TB/s.  Here one persistent workgroup per CU (hipLaunchCooperativeKernel: co-residency is guaranteed by the
 // runtime, or the launch fails) walks through all phases of all layers:
 //
 //     A  RMSNorm(x) -> LDS, qkv projection                      | grid barrier
@@ -20,8 +20,13 @@
 // rows padded by 16 B so that the 16-lane ds_read_b128 groups hit distinct banks.  The weights of the NEXT tile -- or of the next
 // PHASE's first tile -- are requested before the reduction / after arriving at the grid barrier, so HBM keeps streaming through
 // reductions, epilogues and barriers; only the activations wait for the barrier.
-// Grid barrier: monotonic counter in global memory, agent-scope release (every thread) / acquire, bounded spin: a workgroup that
-// waits longer than ~seconds raises the error flag and the kernel unwinds instead of hanging the device.
+// Grid barrier: one epoch flag per workgroup (write-through store; every workgroup polls the whole flag array with one coalesced
+// agent-scope load per round), no cache maintenance (cross-workgroup data is stored write-through into per-layer scratch buffers that
+// are written once and first read after their barrier), bounded spin: a workgroup that waits longer than ~seconds raises the error
+// flag and the kernel unwinds instead of hanging the device.
+// STATUS: parity-green, 3.72 ms per token against 3.45 ms for the launch-per-op path (profiles/r02_decode.txt) -- opt-in
+// (D3D_DECODE_PERSISTENT=1).  What it does not win back: barrier + activation-staging latency per phase that a one-tile register
+// prefetch does not cover, the attention phase (the same ~31 us as the stand-alone kernel), idle CUs in the o_proj / down_proj phases.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
