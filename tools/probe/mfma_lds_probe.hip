@@ -11,6 +11,8 @@
 //   mode 2: waves 0-3 MFMA steps  ||  waves 4-7 LDS steps (partners)   mode 3: every wave: 24 reads then 64 MFMAs per step
 //   mode 4: all 8 waves MFMA steps (two waves share each SIMD's matrix pipe)
 //   mode 5: every wave: 64 MFMAs with the 24 reads of the next (half) step interleaved one per ~3 MFMAs
+//   mode 6 / 7: pure MFMA streams (two waves per SIMD) on operands with RANDOM mantissas, v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16: what
+//               the matrix pipe sustains on real data under the chip's power limit (clock from s_memtime / wall time)
 //
 // build: hipcc --offload-arch=gfx950 -O3 -o mfma_lds_probe mfma_lds_probe.hip ; run: ./mfma_lds_probe
 #include <hip/hip_runtime.h>
@@ -86,6 +88,49 @@ __global__ void __launch_bounds__(512, 2) k_probe(float* out, unsigned long long
             }
         }
     }
+    if constexpr (MODE == 6 || MODE == 7) {
+        // operands with random mantissas (|x| in [0.5, 2)): the toggling of real data, for the power-limited clock
+        uint4 rf[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            uint32_t h = (uint32_t)(tid * 2654435761u) ^ (uint32_t)(i * 40503u) ^ (uint32_t)(blockIdx.x * 97u);
+            auto nx = [&]() { h = h * 1664525u + 1013904223u; const uint32_t a = 0x3f00u | ((h >> 9) & 0x00ffu) | ((h >> 3) & 0x8000u);
+                              h = h * 1664525u + 1013904223u; const uint32_t b = 0x3f00u | ((h >> 9) & 0x00ffu) | ((h >> 3) & 0x8000u); return a | (b << 16); };
+            rf[i] = make_uint4(nx(), nx(), nx(), nx());
+        }
+        using float16v = __attribute__((ext_vector_type(16))) float;
+        float16v big[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) big[i][j] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+            if constexpr (MODE == 6) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&rf[(i + r) % 24]),
+                                                                         *reinterpret_cast<const bf16x8*>(&rf[(i * 5 + r) % 24]), acc[i], 0, 0, 0);
+            } else {
+                // the same 64 x 16384 flop per step as 32 instructions of 32x32x16
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        big[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&rf[(i + r) % 24]),
+                                                                         *reinterpret_cast<const bf16x8*>(&rf[(i * 5 + r) % 24]), big[i], 0, 0, 0);
+            }
+            if ((it & 63) == 63) {          // keep the accumulators bounded
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] *= 1e-3f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) big[i] *= 1e-3f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i & 15][0] += big[i][0] + big[i][7] + big[i][15];
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
@@ -133,6 +178,7 @@ int run(const char* name, float* out, unsigned long long* cyc_d, int iters, Res*
     res->cyc_lds = (MODE == 1 || MODE == 2) ? (double)m_hi / iters : (MODE == 3 ? (double)std::max(m_lo, m_hi) / iters : 0.0);
     printf("%-36s %8.3f ms   cycles/step: mfma waves %8.1f   lds waves %8.1f   (counter rate %.3f GHz)\n", name, best, res->cyc_mfma, res->cyc_lds,
            (double)std::max(m_lo, m_hi) / (best * 1e-3) / 1e9);
+    if (MODE >= 6) printf("   -> %.0f TFLOP/s sustained (256 CUs x 8 waves x 64 x 16384 flop per step)\n", 256.0 * 8 * 64 * 16384.0 * iters / (best * 1e-3) / 1e12);
     return 0;
 }
 
@@ -149,6 +195,11 @@ int main() {
     if (run<3>("3: 2 waves/SIMD, reads then MFMAs", out, cyc, iters, &r3)) return 1;
     if (run<4>("4: MFMA, two waves per SIMD", out, cyc, iters, &r4)) return 1;
     if (run<5>("5: 2 waves/SIMD, reads INTERLEAVED", out, cyc, iters, &r5)) return 1;
+    Res r6, r7;
+    if (run<6>("6: 16x16x32, RANDOM operands", out, cyc, 20000, &r6)) return 1;
+    if (run<7>("7: 32x32x16, RANDOM operands", out, cyc, 20000, &r7)) return 1;
+    if (run<6>("6: 16x16x32, RANDOM operands (again)", out, cyc, 20000, &r6)) return 1;
+    if (run<7>("7: 32x32x16, RANDOM operands (again)", out, cyc, 20000, &r7)) return 1;
     printf("\nwall time per step (64 MFMAs, 24 KiB of ds_read_b128 per wave), ns -- ratios are clock independent:\n");
     const double n0 = r0.ms * 1e6 / iters, n1 = r1.ms * 1e6 / iters, n2 = r2.ms * 1e6 / iters, n3 = r3.ms * 1e6 / iters, n4 = r4.ms * 1e6 / iters;
     printf("  one MFMA wave per SIMD alone   %7.1f ns = %.2f ns per MFMA\n", n0, n0 / 64);
