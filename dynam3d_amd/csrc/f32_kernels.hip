@@ -160,26 +160,41 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ W, float* __re
     }
 }
 
-// y[m, n] = b[n] + sum_k x[m, k] W[n, k], K <= 8: one thread per 4 outputs
+// y[m, n] = b[n] + sum_k x[m, k] W[n, k], K <= 8.  A lane owns 4 output columns and keeps their 4 x 8 weights in registers; a wave walks
+// down the rows of its block (row r, r + 4, ...: the row's K inputs are one wave-uniform read), storing 1 KiB of consecutive outputs per
+// instruction.  (The first version re-read the weights for every output: 50 us for 4 600 x 768 outputs; the write alone is ~3 us.)
+constexpr int SMALLK_ROWS = 64;           // rows per workgroup (4 waves x 16)
 template <int EPI>
-__global__ void k_linear_smallk(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ y, int M,
-                                int N, int K, int64_t ldx, int64_t ldy) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int n4 = N >> 2;
-    if (i >= (int64_t)M * n4) return;
-    const int m = (int)(i / n4), n = (int)(i % n4) * 4;
-    float xv[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) xv[k] = k < K ? x[(int64_t)m * ldx + k] : 0.f;
-    float o[4];
+__global__ void __launch_bounds__(256)
+k_linear_smallk(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ y, int M,
+                int N, int K, int64_t ldx, int64_t ldy) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + lane) * 4;
+    const bool live = n < N;
+    float w[4][8], bb[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float s = 0.f;
-        for (int k = 0; k < K; ++k) s = fmaf(xv[k], W[(int64_t)(n + r) * K + k], s);
-        o[r] = s + bias[n + r];
-        if constexpr (EPI == F_BIAS_GELU) o[r] = gelu_erf(o[r]);
+        bb[r] = live ? bias[n + r] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[r][k] = (live && k < K) ? W[(int64_t)(n + r) * K + k] : 0.f;
     }
-    *reinterpret_cast<float4*>(y + (int64_t)m * ldy + n) = float4{o[0], o[1], o[2], o[3]};
+    const int m_end = min(M, (int)(blockIdx.y + 1) * SMALLK_ROWS);
+    for (int m = blockIdx.y * SMALLK_ROWS + wave; m < m_end; m += 4) {
+        const float* xr = x + (int64_t)m * ldx;
+        float xv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xv[k] = k < K ? xr[k] : 0.f;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s = fmaf(xv[k], w[r][k], s);      // (k >= K: + 0 * 0, exact)
+            o[r] = s + bb[r];
+            if constexpr (EPI == F_BIAS_GELU) o[r] = gelu_erf(o[r]);
+        }
+        if (live) *reinterpret_cast<float4*>(y + (int64_t)m * ldy + n) = float4{o[0], o[1], o[2], o[3]};
+    }
 }
 
 // y[m, n] = b[n] + sum_k x[m, k] W[n, k], N <= 8: one wave per row
@@ -319,8 +334,7 @@ int32_t d3d_linear_smallk_f32(const float* x, const float* W, const float* bias,
         d3d_set_error_("d3d_linear_smallk_f32: 1 <= K <= 8, N % 4 == 0, ldy % 4 == 0");
         return D3D_EINVAL;
     }
-    const int64_t n = (int64_t)M * (N / 4);
-    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    dim3 grid((unsigned)((N / 4 + 63) / 64), (unsigned)((M + SMALLK_ROWS - 1) / SMALLK_ROWS)), block(256);
     if (gelu)
         hipLaunchKernelGGL((k_linear_smallk<F_BIAS_GELU>), grid, block, 0, (hipStream_t)stream, x, W, bias, y, M, N, K, ldx, ldy);
     else
