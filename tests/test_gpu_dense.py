@@ -152,6 +152,33 @@ def test_gemm_skinny_decode_rows(hd, dt, tol):
         assert torch.equal(hd.linear(x, w, None, None, r), hd.linear(x, w, None, None, r))
 
 
+def test_gemm_output_row_stride_not_16_byte_aligned(hd):
+    """The 256-tile kernels and the transposed epilogue of the 128-tile kernel store 16 bytes per lane: an output whose row stride is
+    a multiple of 4 but not of 8 elements (rows not 16-byte aligned) must take the 8-byte store path and still be right -- d3d_gemm_nt
+    routes it to the 128 x 128 kernel with direct stores; forcing a 256-tile kernel on it is refused."""
+    import ctypes as C
+    from dynam3d_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(12)
+    M, N, K = 2304, 3072, 512
+    x = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    r = torch.randn(M, N, device="cuda").to(torch.bfloat16)
+    ldc = N + 4
+    out = torch.zeros(M, ldc, device="cuda", dtype=torch.bfloat16)
+    res = torch.zeros(M, ldc, device="cuda", dtype=torch.bfloat16)
+    res[:, :N] = r
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.d3d_gemm_nt(p(x), p(w), p(out), None, p(res), M, N, K, K, K, ldc, 0, 4, st)
+    assert rc == 0
+    ref = epi_ref("res", x.float() @ w.float().t(), None, r, torch.bfloat16)
+    assert rel(out[:, :N].float(), ref) < 1e-3
+    assert float(out[:, N:].abs().max()) == 0.0                                   # nothing written past the row
+    rc = lib.d3d_gemm_nt_tile(p(x), p(w), p(out), None, p(res), M, N, K, K, K, ldc, 0, 4, 260, st)
+    assert rc != 0
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_gemm_skinny_fused_rmsnorm(hd, dt):
     """d3d_gemm_nt_rmsnorm (decode: RMSNorm applied to the raw residual stream inside the weight-streaming GEMM) is BIT-identical to
