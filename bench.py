@@ -86,7 +86,7 @@ def _best_threads(limit):
     return best
 
 
-def cpu_baseline(cfg, seed, B, warm_steps):
+def cpu_baseline(cfg, seed, B, warm_steps, gpu_lengths=None):
     """The whole-step float32 oracle ("port", oracle/step_oracle.py) MEASURED on the host cores at the benchmark's operating point:
     B environments, memory advanced `warm_steps` steps (3D-memory oracle on seeded unit-norm grid features -- the towers do not
     touch the memory), then ONE full step timed end to end: both ViT-L/14@336 towers on B frames, the 3D-token builder, the prefix
@@ -120,9 +120,14 @@ def cpu_baseline(cfg, seed, B, warm_steps):
     st = {k: round(v, 3) for k, v in orc.timing.items()}
     out = dict(value=round(B / measured, 5), unit="env-steps/s", cores=n_threads, physical_cores=phys, logical_cpus=os.cpu_count(), kind="port",
                sample=("ONE full warm step measured end to end, %d environments, float32 oracle (oracle/step_oracle.py): CLIP ViT-L/14@336 + llava ViT-L on %d frames, "
-                       "3D-token builder (memory advanced %d steps), prefix, Phi-3-mini prefill over all %d layers at S=%s (right-padded to %d); %d torch threads "
-                       "(fastest of a 1 s GEMM probe over 8..%d = the physical cores)"
-                       % (B, B, warm_steps, cfg.llm.layers, orc.last_lengths, max(orc.last_lengths), n_threads, phys)),
+                       "3D-token builder, prefix, Phi-3-mini prefill over all %d layers at S=%s (right-padded to %d); %d torch threads "
+                       "(fastest of a 1 s GEMM probe over 8..%d = the physical cores).  Operating point: the SAME synthetic episodes and the SAME memory step as the "
+                       "first step the GPU leg times (memory advanced %d steps); the untimed advance feeds the 3D memory seeded unit-norm grid features instead of "
+                       "running CLIP on the host for every advance step (9 s each), so merge decisions -- and with them Ni/Nz and S -- differ from the GPU leg's: "
+                       "S here sums to %d tokens, the GPU leg's first timed step to %s"
+                       % (B, B, cfg.llm.layers, orc.last_lengths, max(orc.last_lengths), n_threads, phys, warm_steps, sum(orc.last_lengths),
+                          sum(gpu_lengths) if gpu_lengths else "n/a")),
+               memory_steps_advanced=warm_steps,
                seconds_measured=round(measured, 2), stages=st, seconds_weights=round(t_w, 1), seconds_memory_warmup=round(t_warm, 1))
     # n = 8 threads (comparability with the survey container's probe), bounded: one environment's frame through both towers,
     # the B-environment memory step, Phi-3 on 2 of the layers; the full-step figure is the sum scaled to B frames / all layers.
@@ -208,8 +213,13 @@ def main():
 
     if rank == 0:
         ms = dt / a.steps * 1e3
-        fl = step_flops(cfg, lengths_seen[-1], B, pruned_last_layer=bool(getattr(net.llm, "PRUNE_LAST_LAYER", False)))
-        rows_gemm = getattr(net.llm, "last_packed_rows", None) or B * max(lengths_seen[-1])   # rows the GEMM actually processes
+        pruned = bool(getattr(net.llm, "PRUNE_LAST_LAYER", False))
+        # Algorithmic FLOPs are accumulated PER TIMED STEP (the prompts grow by ~30 tokens per step as the memory fills): the step figures
+        # are sums over the timed steps divided by the timed wall time, the launch figures sums over the timed launches.
+        fl_steps = [step_flops(cfg, L, B, pruned_last_layer=pruned) for L in lengths_seen]
+        fl = {k: sum(f[k] for f in fl_steps) / len(fl_steps) for k in fl_steps[0]}          # mean per step
+        tokens_steps = [sum(L) for L in lengths_seen]
+        rows_gemm = getattr(net.llm, "last_packed_rows", None) or B * max(lengths_seen[-1])   # rows the last step's GEMMs processed
         tsum = TIMER.summary()
         n_gu, ms_gu_raw = tsum.get("phi3.gate_up_proj", (0, float("nan")))
         # A HIP-event bracket on the launching stream measures the launch PLUS what the two event records cost there (each waits for the
@@ -218,42 +228,53 @@ def main():
         _, ms_empty = tsum.get("phi3.event_pair_overhead", (0, 0.0))
         ms_gu = ms_gu_raw - ms_empty
         l = cfg.llm
-        gu_flops = 2.0 * sum(lengths_seen[-1]) * l.hidden * 2 * l.mlp                     # ALGORITHMIC: real tokens only
+        recs = TIMER.records("phi3.gate_up_proj")                                           # (ms, {rows: real tokens of THAT launch})
+        gu_flops_total = sum(2.0 * r.get("rows", tokens_steps[-1]) * l.hidden * 2 * l.mlp for _, r in recs)   # ALGORITHMIC: real tokens only
+        gu_flops = gu_flops_total / max(len(recs), 1)                                       # mean per launch
         achieved = gu_flops / (ms_gu * 1e-3) / 1e12 if n_gu else float("nan")
         st = net.feature_fields.state
         traffic, traffic_note = None, None
-        pj = os.path.join(ROOT, "profiles", "r02_pmc_gate_up.json")
+        import glob
+        pjs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_gate_up.json")))       # the latest round's PMC passes
+        pj = pjs[-1] if pjs else ""
         if os.path.isfile(pj) and dict(D.BACKEND)["linear"] == "hip":
             # Fabric-side bytes per launch of this kernel: counters cannot be read inside an un-profiled run, so this is the figure of THIS
-            # ROUND's rocprofv3 --pmc passes over the same kernel (profiles/r02_pmc_gate_up.json: 2 * FETCH_SIZE + WRITE_SIZE, separate
+            # ROUND's rocprofv3 --pmc passes over the same kernel (profiles/rNN_pmc_gate_up.json: 2 * FETCH_SIZE + WRITE_SIZE, separate
             # passes; FETCH_SIZE counts 128-B requests at 64 B on gfx950, MI355X_MICROARCH.md), scaled by the rows of this run.
             pm = json.load(open(pj))
             traffic = int(pm["hbm_bytes_per_launch"] * rows_gemm / float(pm["rows"]))
-            traffic_note = ("from_profile: profiles/r02_pmc_gate_up.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this round's kernel at M = %d), "
-                            "scaled by launched rows; includes Infinity-Cache hits (algorithmic bytes %d)" % (pm["rows"], int(pm["algorithmic_bytes"] * rows_gemm / float(pm["rows"]))))
+            traffic_note = ("from_profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, the kernel at M = %d), "
+                            "scaled by launched rows; includes Infinity-Cache hits (algorithmic bytes %d)" % (os.path.basename(pj), pm["rows"], int(pm["algorithmic_bytes"] * rows_gemm / float(pm["rows"]))))
         out = {
             "metric": "nav steps/sec (RGB-D obs->action logits) at batch=8", "value": round(B * a.steps * a.gpus / dt, 3), "unit": "env-steps/s",
             "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[2]: full Dynam3D-VLN step (3D tokens + llava-phi-3-mini prefill -> action logits), batch=8 synthetic 224x224 RGB-D, 1 MI355X per rank",
-                       "batch_per_gpu": B, "operating_point": f"warm (memory advanced {a.warm_steps} steps)", "S_tokens": lengths_seen[-1],
+                       "batch_per_gpu": B, "operating_point": (f"warm: the timed steps are memory steps {a.warm_steps + a.warmup}..{total - 1} of the synthetic episodes "
+                                           f"({a.warm_steps} untimed advance steps + {a.warmup} warm-up steps before them)"),
+                       "memory_steps_timed": [a.warm_steps + a.warmup, total - 1],
+                       "S_tokens_first_timed_step": lengths_seen[0], "S_tokens_last_timed_step": lengths_seen[-1], "S_tokens": lengths_seen[-1],
+                       "real_tokens_per_timed_step": tokens_steps, "mean_real_tokens_per_step": round(sum(tokens_steps) / len(tokens_steps), 1),
                        "Ni": net.last_counts["Ni"], "Nz": net.last_counts["Nz"], "rows_per_env": st.count(0, st.ROWS),
                        "instances_per_env": st.count(0, st.LIVE), "clip_dtype": str(cfg.clip_dtype), "llm_dtype": str(cfg.llava_dtype),
                        "token_builder_dtype": "float32", "parallelism": f"episode-parallel x{a.gpus} (no data-path collective)",
                        "dense_backend": dict(D.BACKEND), "strict_hip": bool(D.STRICT),
                        "dense_dispatch_per_step": {k: round(v / a.steps, 2) for k, v in D.counts()["hip"].items()},
                        "fallbacks": int(sum(D.counts()["fallback"].values()))},
-            "roofline": {"bound": "mfma", "kernel": "phi3.gate_up_proj GEMM + fused SwiGLU (sum(S_b) x 3072 x 16384, bf16): k_gemm_nt_256<bf16,SwiGLU> on the full rounds (+ k_gemm_nt<bf16,SwiGLU> on the last rows when the last round is at most half full); avg_launch_ms covers the whole projection", "gemm_rows_launched": rows_gemm, "real_tokens": sum(lengths_seen[-1]), "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": "phi3.gate_up_proj GEMM + fused SwiGLU (sum(S_b) x 3072 x 16384, bf16): k_gemm_nt_256<bf16,SwiGLU> on the full rounds (+ k_gemm_nt<bf16,SwiGLU> on the last rows when the last round is at most half full); avg_launch_ms covers the whole projection", "gemm_rows_launched_last_step": rows_gemm, "mean_real_tokens_per_launch": round(gu_flops / (2.0 * l.hidden * 2 * l.mlp), 1),
+                         "algorithmic_gflop_per_launch_mean": round(gu_flops / 1e9, 2), "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "launches_timed": n_gu, "avg_launch_ms": round(ms_gu, 4), "avg_launch_ms_event_bracket": round(ms_gu_raw, 4),
                          "event_pair_overhead_ms": round(ms_empty, 4),
+                         "accounting": "achieved = (sum over the timed launches of 2 * real_tokens * 3072 * 16384) / (sum of their HIP-event durations - event-pair overhead); "
+                                       "step_* = mean over the timed steps of the algorithmic FLOPs at that step's own S_b",
                          "step_total_tflop": round(fl["total"] / 1e12, 2), "step_frac_of_peak": round(fl["total"] / (ms * 1e-3) / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4),
                          "step_flop_split_tflop": {k: round(v / 1e12, 3) for k, v in fl.items() if k != "total"}},
         }
         do_cpu = a.cpu_baseline == "on" or (a.cpu_baseline == "auto" and a.gpus == 1)
         if do_cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, a.seed, B, a.warm_steps)
+                out["cpu_baseline"] = cpu_baseline(cfg, a.seed, B, a.warm_steps + a.warmup, lengths_seen[0])
             except Exception as e:  # never lose the GPU line because the host baseline failed
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)

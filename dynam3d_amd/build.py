@@ -25,6 +25,7 @@ HIP_SOURCES = [
     ("f32_kernels.hip", ["-ffp-contract=off"]),
     ("gemm_kernels.hip", ["-ffp-contract=fast"]),
     ("attn_kernels.hip", ["-ffp-contract=fast"]),
+    ("attn2_kernels.hip", ["-ffp-contract=fast"]),
     ("decode_kernels.hip", ["-ffp-contract=fast"]),
     ("render_kernels.hip", ["-ffp-contract=off"]),
 ]

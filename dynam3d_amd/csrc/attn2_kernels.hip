@@ -1,0 +1,417 @@
+// attn2_kernels.hip -- second-generation fused self-attention forward for gfx950 (bf16/fp16, head_dim 64 / 96, causal or full, dense or
+// packed variable-length, optional sliding window), reading q/k/v in place from the fused QKV projection buffer.
+//
+// What changed against attn_kernels.hip::k_flash_attn (kept as the A/B baseline, D3D_ATTN_V2=0) and why -- that kernel ran at 0.15-0.17 of
+// the MFMA peak with the matrix pipe busy 13 % and a SIMD issuing VALU 34 % of the time (profiles/r01_pmc_attn_vit.txt):
+//   * v_mfma_f32_32x32x16 instead of 16x16x32.  S^T = K Q^T on 32x32 tiles puts ONE query column in a lane (and its partner lane + 32):
+//     a lane holds 32 of the 64 scores of its query, so the row maximum / row sum are 31 register-local operations plus ONE
+//     v_permlane32_swap step (the 16x16 layout held two query sets per lane, each with two cross-lane steps), there is one running
+//     max / sum / rescale decision per lane instead of two, and half as many MFMA and LDS-read instructions are issued per FLOP.
+//   * P^T is ALREADY the B operand of O^T = V^T P^T: a lane's accumulator registers hold keys {4*hi + 8*j + r} of each 32-key block for
+//     its query; declaring k-slot (hi*8 + jj*4 + r) of a 16-key MFMA step to be key (16*s + 8*jj + 4*hi + r) makes the lane's own 8
+//     packed values the B fragment -- no cross-lane movement between the two GEMMs -- and the V^T fragment (A operand) in that slot
+//     order is two ds_read_b64_tr_b16 of [4 keys][16 dims] blocks.
+//   * K/V tiles are DOUBLE-buffered in LDS with ONE barrier per key tile: tile t+1 is written (from registers, loaded a tile earlier)
+//     between the softmax and the PV product of tile t, into the buffer every wave finished reading before the previous barrier.
+//   * diagonal tiles: a 32-key block entirely above a wave's diagonal is skipped (its QK^T and PV MFMAs and its softmax work).
+//   * the epilogue exchanges half-rows between lane pairs (v_permlane32_swap) and stores 16 bytes per instruction.
+//   * sliding window (Phi-3-mini-4k: 2047 keys): key <= query - window is masked, tiles entirely outside the window are never visited.
+//   * XCD-aware grid (see the kernel): the query blocks of one (sequence, head) share an L2.
+// Measured against v1 in one process (tools/bench_attn_ab.py): Phi-3 packed causal 8 x 1024: 107 -> 93 us, the step's lengths 100 -> 92 us, ViT
+// 8 x 577: 28.0 -> 25.6 us.  In-kernel stamps of this structure and of a software-pipelined / hand-scheduled variant (QK^T of tile t+1
+// beside the softmax of tile t) say what is left: a wave's tile costs ~1 000 cycles of VALU issue (32 v_exp_f32 at a
+// quarter rate + ~120 plain instructions) against 768 cycles of matrix pipe, and two waves share one SIMD's VALU.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/dynam3d_hip.h"
+#include "d3d_common.h"
+
+namespace {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using float16v = __attribute__((ext_vector_type(16))) float;
+using float2v = __attribute__((ext_vector_type(2))) float;
+using v4s = __attribute__((ext_vector_type(4))) short;
+
+constexpr int BQ = 128, BKV = 64, NT = 256;
+
+template <bool BF16>
+__device__ __forceinline__ float16v mfma32(const uint4& a, const uint4& b, float16v c) {
+    if constexpr (BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&a), *reinterpret_cast<const half8*>(&b), c, 0, 0, 0);
+}
+
+template <bool BF16>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    if constexpr (BF16) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t r = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);      // v_cvt_pk_bf16_f32 (RNE)
+        return *reinterpret_cast<const uint32_t*>(&r);
+    } else {
+        const __half2 h = __floats2half2_rn(lo, hi);
+        return *reinterpret_cast<const uint32_t*>(&h);
+    }
+}
+
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// op(v, value of lane ^ 32): v_permlane32_swap exchanges the upper half of vdst with the lower half of src; with both operands holding
+// the same value, op(vdst', src') is the xor-32 butterfly.  Inline asm: the builtin folds away when both operands are the same SSA
+// value; s_nop 1 = the two wait states a VALU write needs before v_permlane32_swap reads it (LLVM gfx950 hazard rule).
+__device__ __forceinline__ float pair_max(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+    return a;
+}
+__device__ __forceinline__ float pair_sum(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_add_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+    return a;
+}
+
+template <bool BF16, int HD, bool CAUSAL>
+__global__ void __launch_bounds__(NT, 2)
+k_flash_attn32(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, int64_t row_stride, int64_t batch_stride, int q_off, int k_off,
+               int v_off, float scale_log2e, int seq_len, const int32_t* __restrict__ cu, int n_qblocks, int window, int nx, int B) {
+    constexpr int KS = HD / 16;              // 16-deep MFMA steps over head_dim (QK^T)
+    constexpr int DB = HD / 32;              // 32-wide head-dim blocks (PV)
+    constexpr int CH = HD / 8;               // 16-byte chunks per row
+    constexpr int KCH = HD == 96 ? 16 : 8;   // chunk slots per K row in LDS (power of two: XOR swizzle)
+    constexpr int KST = KCH * 8;             // K row stride (elements): 256 B / 128 B
+    constexpr int VST = 96;                  // V row stride (elements) = 192 B = 64 (mod 256): the 4 rows x 64 B a half-wave's transposing
+                                             // read touches fall into 4 different quarter-rows of the 256-byte bank space
+    constexpr int KBUF = BKV * KST, VBUF = BKV * VST;
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[2 * KBUF];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[2 * VBUF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and PROVABLY so: tile / block activity below are scalar branches
+    const int li = lane & 31, hi = lane >> 5;
+    // XCD-aware placement.  Workgroups go to the 8 XCDs round-robin by linear id, each XCD has its own L2, and every query block of a
+    // (sequence, head) streams the SAME K/V rows: with (x, head, batch) as the grid the blocks of one head landed on different XCDs and each
+    // pulled its own copy through the fabric (~0.45 GB of K/V reads per Phi-3 launch, 192-byte row pieces at an 18 KB stride).  Now the `nx`
+    // workgroups of one (sequence, head) are consecutive slots of ONE XCD (dispatched together, walking the key tiles in step), and
+    // neighbouring slots are neighbouring heads of the same sequence, whose 192-byte row pieces share 128-byte lines: -7 ... -14 %.
+    int h, b, xq;
+    {
+        const int lin = blockIdx.x, G = H * B, G8 = G & ~7;
+        if (lin < G8 * nx) {
+            const int xcd = lin & 7, slot = lin >> 3, k = slot / nx;
+            xq = slot - k * nx;
+            if ((H & 7) == 0) {
+                const int hp = H >> 3;                                       // heads per XCD
+                h = xcd * hp + k % hp;
+                b = k / hp;
+            } else {
+                const int g = xcd + 8 * k;
+                h = g % H;
+                b = g / H;
+            }
+        } else {
+            const int r = lin - G8 * nx, g = G8 + r / nx;
+            xq = r % nx;
+            h = g % H;
+            b = g / H;
+        }
+    }
+    int64_t row0 = (int64_t)b * S;
+    const uint16_t* base = qkv + (int64_t)b * batch_stride;
+    if (cu) {
+        row0 = cu[b];
+        S = cu[b + 1] - cu[b];
+        seq_len = S;
+        n_qblocks = (S + BQ - 1) / BQ;
+        base = qkv + row0 * row_stride;
+    }
+    if (CAUSAL ? xq >= (n_qblocks + 1) / 2 : xq >= n_qblocks) return;
+    const uint16_t* Qp = base + (int64_t)(q_off + h) * HD;
+    const uint16_t* Kp = base + (int64_t)(k_off + h) * HD;
+    const uint16_t* Vp = base + (int64_t)(v_off + h) * HD;
+
+    // K swizzle: chunk c of row r lives in slot c ^ f(r); f makes the 16 rows of a ds_read_b128 lane group hit 16 different 16-byte
+    // slots of the 256-byte bank space (hd 96: 256-byte rows, f = r & 15; hd 64: 128-byte rows alternate halves, f = (r >> 1) & 7)
+    auto kswz = [](int r) { return HD == 96 ? (r & 15) : ((r >> 1) & 7); };
+
+    constexpr int NK = (BKV * CH) / NT;      // 3 (hd 96) / 2 (hd 64) 16-byte chunks of K (and of V) per thread and tile
+    static_assert(NK == 2 || NK == 3, "tile shape");
+    uint4 kr0, kr1, kr2 = make_uint4(0, 0, 0, 0), vr0, vr1, vr2 = make_uint4(0, 0, 0, 0);
+    auto ld_kv = [&](const uint16_t* P, int key0_, int i) -> uint4 {          // rows beyond the sequence are clamped (valid memory, masked later)
+        const int c = tid + i * NT;
+        const int kr = min(key0_ + c / CH, S - 1);
+        return *reinterpret_cast<const uint4*>(P + (int64_t)kr * row_stride + (c % CH) * 8);
+    };
+    auto st_k = [&](uint16_t* Kb, int i, const uint4& v) {
+        const int c = tid + i * NT, r = c / CH;
+        *reinterpret_cast<uint4*>(Kb + r * KST + (((c % CH) ^ kswz(r)) << 3)) = v;
+    };
+    auto st_v = [&](uint16_t* Vb, int i, const uint4& v) {
+        const int c = tid + i * NT;
+        *reinterpret_cast<uint4*>(Vb + (c / CH) * VST + (c % CH) * 8) = v;
+    };
+#define FA_LOAD_TILE(T)                                        \
+    {                                                          \
+        const int k0_ = (T) * BKV;                             \
+        kr0 = ld_kv(Kp, k0_, 0);                               \
+        kr1 = ld_kv(Kp, k0_, 1);                               \
+        if constexpr (NK > 2) kr2 = ld_kv(Kp, k0_, 2);         \
+        vr0 = ld_kv(Vp, k0_, 0);                               \
+        vr1 = ld_kv(Vp, k0_, 1);                               \
+        if constexpr (NK > 2) vr2 = ld_kv(Vp, k0_, 2);         \
+    }
+#define FA_STORE_TILE(BUF)                                     \
+    {                                                          \
+        uint16_t* Kb_ = Ks + (BUF) * KBUF;                     \
+        uint16_t* Vb_ = Vs + (BUF) * VBUF;                     \
+        st_k(Kb_, 0, kr0);                                     \
+        st_k(Kb_, 1, kr1);                                     \
+        if constexpr (NK > 2) st_k(Kb_, 2, kr2);               \
+        st_v(Vb_, 0, vr0);                                     \
+        st_v(Vb_, 1, vr1);                                     \
+        if constexpr (NK > 2) st_v(Vb_, 2, vr2);               \
+    }
+    using lds_v4s = __attribute__((address_space(3))) v4s;
+    // V fragment base (A operand of O^T = V^T P^T through the transposing read): lane addresses key 16s + 8jj + 4hi + (l & 15) / 4,
+    // dims 32d + 16 ((l >> 4) & 1) + 4 (l & 3) and receives dim 32d + li of 4 consecutive keys
+    const int v_off0 = (hi * 4 + ((lane & 15) >> 2)) * VST + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+
+  for (int pass = 0; pass < (CAUSAL ? 2 : 1); ++pass) {
+    const int qb = CAUSAL ? (pass == 0 ? n_qblocks - 1 - xq : xq) : xq;
+    if (CAUSAL && pass == 1 && qb == n_qblocks - 1 - xq) break;          // odd count: the middle block stands alone
+    const int q0 = qb * BQ, qw = q0 + wave * 32;
+    const int qrow = qw + li;                                            // this lane's query
+
+    // Q fragments (B operand of S^T = K Q^T): lane holds Q[qrow][ks*16 + hi*8 .. +7]
+    uint4 qf[KS];
+    {
+        const int q = qrow < S ? qrow : S - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(Qp + (int64_t)q * row_stride + ks * 16 + hi * 8);
+    }
+    float16v oacc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+
+    const int kv_len = CAUSAL ? min(seq_len, q0 + BQ) : seq_len;
+    const int n_tiles = (kv_len + BKV - 1) / BKV;
+    // sliding window: the first key any query of this block may see is q0 - window + 1 -> start at its tile
+    const int t_first = (window > 0 && q0 - window + 1 > 0) ? (q0 - window + 1) / BKV : 0;
+    // this lane's visible key range [kmin, kmax]
+    const int kmax = CAUSAL ? min(qrow, seq_len - 1) : seq_len - 1;
+    const int kmin = window > 0 ? qrow - window + 1 : 0;
+
+    FA_LOAD_TILE(t_first)
+    FA_STORE_TILE(0)
+    if (t_first + 1 < n_tiles) FA_LOAD_TILE(t_first + 1)
+    __syncthreads();
+
+    for (int t = t_first; t < n_tiles; ++t) {
+        const int cur = (t - t_first) & 1;
+        const int key0 = t * BKV;
+        const uint16_t* Kb = Ks + cur * KBUF;
+        const uint16_t* Vb = Vs + cur * VBUF + v_off0;
+        // wave-uniform activity: the tile (or its second 32-key block) may lie entirely above this wave's diagonal / below its window
+        const bool tile_on = !(CAUSAL && key0 > qw + 31) && !(window > 0 && key0 + BKV - 1 <= qw - window);
+        const bool blk1_on = tile_on && !(CAUSAL && key0 + 32 > qw + 31);
+        uint4 pf[4];
+        if (tile_on) {
+            // ---- S^T = K Q^T : st[b][4j + r] = S[key0 + 32b + 8j + 4hi + r][qrow] ---------------------------------------------------
+            // K fragments: all KS reads of block 0 are issued up front; block 1's reads are issued one behind each MFMA of block 0's chain
+            // (hipcc left to itself kept two reads in flight and waited for each pair: the LDS latency was exposed three times per chain)
+            float16v st[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[0][r] = 0.f; st[1][r] = 0.f; }
+            uint4 kfa[KS], kfb[KS];
+            const uint16_t* Ka = Kb + li * KST;
+            const uint16_t* Kc = Kb + (32 + li) * KST;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kfa[ks] = *reinterpret_cast<const uint4*>(Ka + (((ks * 2 + hi) ^ kswz(li)) << 3));
+            if (blk1_on) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    kfb[ks] = *reinterpret_cast<const uint4*>(Kc + (((ks * 2 + hi) ^ kswz(32 + li)) << 3));
+                    st[0] = mfma32<BF16>(kfa[ks], qf[ks], st[0]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) st[1] = mfma32<BF16>(kfb[ks], qf[ks], st[1]);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one ds_read (block 1, step ks)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA  (block 0, step ks)
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) st[0] = mfma32<BF16>(kfa[ks], qf[ks], st[0]);
+            }
+            // ---- masking (diagonal tiles, the tile that crosses seq_len, the window edge): key - key0 - 4hi in [lo_, hi_] is visible -------
+            const bool need_mask = (CAUSAL && key0 + BKV - 1 > qw) || (key0 + BKV > seq_len) || (window > 0 && key0 <= qw + 31 - window);
+            if (need_mask) {
+                const int lo_ = kmin - key0 - hi * 4, hi_ = kmax - key0 - hi * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o_ = j * 8 + r;
+                        if (o_ > hi_ || o_ < lo_) st[0][4 * j + r] = -INFINITY;
+                        if (o_ + 32 > hi_ || o_ + 32 < lo_) st[1][4 * j + r] = -INFINITY;
+                    }
+            }
+            // ---- online softmax, base 2, one query per lane pair ------------------------------------------------------------------------
+            float tmax = max3(st[0][0], st[0][1], st[0][2]);
+#pragma unroll
+            for (int r = 3; r + 1 < 16; r += 2) tmax = max3(tmax, st[0][r], st[0][r + 1]);
+            tmax = fmaxf(tmax, st[0][15]);
+            if (blk1_on) {
+#pragma unroll
+                for (int r = 0; r + 1 < 16; r += 2) tmax = max3(tmax, st[1][r], st[1][r + 1]);
+            }
+            tmax = pair_max(tmax);
+            const float tm = tmax * scale_log2e;
+            const bool keep = __all(tm <= m_i + 8.0f);                     // deferred rescale: P stays <= 2^8
+            const float m_new = keep ? m_i : fmaxf(m_i, tm);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;           // a row with no visible key yet (window / padding): exp2(-inf) = 0
+            const float alpha = keep ? 1.0f : __builtin_amdgcn_exp2f(m_i - m_use);
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[0][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[0][r], scale_log2e, -m_use));
+                rs += st[0][r];
+            }
+            if (blk1_on) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[1][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[1][r], scale_log2e, -m_use));
+                    rs += st[1][r];
+                }
+            }
+            rs = pair_sum(rs);
+            l_i = l_i * alpha + rs;
+            m_i = m_new;
+            if (!keep) {
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+            }
+            // P^T fragments: MFMA step s covers keys 16s .. 16s+15 of the tile; k-slot (hi*8 + jj*4 + r) = key 16s + 8jj + 4hi + r
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int kb = s >> 1, j = 2 * (s & 1);
+                pf[s].x = pack2<BF16>(st[kb][4 * j + 0], st[kb][4 * j + 1]);
+                pf[s].y = pack2<BF16>(st[kb][4 * j + 2], st[kb][4 * j + 3]);
+                pf[s].z = pack2<BF16>(st[kb][4 * j + 4], st[kb][4 * j + 5]);
+                pf[s].w = pack2<BF16>(st[kb][4 * j + 6], st[kb][4 * j + 7]);
+            }
+        }
+        // ---- stage tile t+1 (in registers since the previous iteration) into the other buffer; request tile t+2 ----------------------------
+        if (t + 1 < n_tiles) {
+            FA_STORE_TILE(cur ^ 1)
+            if (t + 2 < n_tiles) FA_LOAD_TILE(t + 2)
+        }
+        // ---- O^T += V^T P^T ------------------------------------------------------------------------------------------------------------
+        if (tile_on) {
+            auto ld_vf = [&](int s_, int d_) -> uint4 {
+                const uint16_t* vb = Vb + s_ * 16 * VST + d_ * 32;
+                const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)vb);
+                const v4s hv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(vb + 8 * VST));
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hv);
+                return make_uint4(l2.x, l2.y, h2.x, h2.y);
+            };
+            // steps in (s, d) order (DB independent accumulators back to back); the V fragments of step (s + 1, d) are requested before the
+            // MFMA of step (s, d) is issued, so DB steps (2 DB transposing reads) are always in flight
+            uint4 vf[2][DB];
+#pragma unroll
+            for (int d = 0; d < DB; ++d) vf[0][d] = ld_vf(0, d);
+            if (blk1_on) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int d = 0; d < DB; ++d) {
+                        if (s + 1 < 4) vf[(s + 1) & 1][d] = ld_vf(s + 1, d);
+                        oacc[d] = mfma32<BF16>(vf[s & 1][d], pf[s], oacc[d]);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int d = 0; d < DB; ++d) {
+                        if (s + 1 < 2) vf[(s + 1) & 1][d] = ld_vf(s + 1, d);
+                        oacc[d] = mfma32<BF16>(vf[s & 1][d], pf[s], oacc[d]);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+            }
+        }
+        __syncthreads();          // tile t+1 is visible; every wave is done with buffer `cur`
+    }
+    // ---- epilogue: lane holds O[qrow][32d + 8j + 4hi + r]; lane pairs exchange so that each stores 16 contiguous bytes ---------------------
+    const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
+    uint16_t* op = out + ((row0 + qrow) * H + h) * HD;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {                 // j = 2jp, 2jp+1: dims 32d + 16jp + {0..3 (hi 0), 4..7 (hi 1), 8..11 (hi 0), 12..15 (hi 1)}
+            uint32_t a0 = pack2<BF16>(oacc[d][8 * jp + 0] * inv, oacc[d][8 * jp + 1] * inv), a1 = pack2<BF16>(oacc[d][8 * jp + 2] * inv, oacc[d][8 * jp + 3] * inv);
+            uint32_t b0 = pack2<BF16>(oacc[d][8 * jp + 4] * inv, oacc[d][8 * jp + 5] * inv), b1 = pack2<BF16>(oacc[d][8 * jp + 6] * inv, oacc[d][8 * jp + 7] * inv);
+            // v_permlane32_swap(vdst = a, src = b) swaps upper-half(a) with lower-half(b): a lower lane ends with [own a | upper's a] = dims
+            // 0..7 of the group pair, an upper lane with [lower's b | own b] = dims 8..15
+            const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            if (qrow < S) *reinterpret_cast<uint4*>(op + d * 32 + jp * 16 + hi * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+    }
+  }   // pass
+#undef FA_LOAD_TILE
+#undef FA_STORE_TILE
+}
+
+}  // namespace
+
+extern "C" {
+
+// Same contract as d3d_flash_attention (attn_kernels.hip) plus `window` (0 = none; > 0: a query attends to the last `window` keys,
+// itself included -- HF sliding-window masking, transformers 4.46 `_prepare_4d_causal_attention_mask_with_cache_position`).
+int32_t d3d_flash_attention_v2(const void* qkv, void* out, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride, int64_t batch_stride,
+                               int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len, const int32_t* cu_seqlens, int32_t window,
+                               int32_t dtype, void* stream) {
+    if (B <= 0 || S <= 0) return D3D_OK;
+    if ((head_dim != 64 && head_dim != 96) || (row_stride & 7) || (batch_stride & 7) || window < 0 || (window > 0 && !causal)) {
+        d3d_set_error_("d3d_flash_attention_v2: head_dim must be 64 or 96; strides multiples of 8 elements; a window needs causal");
+        return D3D_EINVAL;
+    }
+    const float sl2 = 1.4426950408889634f / sqrtf((float)head_dim);
+    hipStream_t s = (hipStream_t)stream;
+    const uint16_t* q = (const uint16_t*)qkv;
+    uint16_t* o = (uint16_t*)out;
+    const int nqb = (S + BQ - 1) / BQ;
+    if (window >= S) window = 0;                                       // no query is further than S - 1 keys from the first key
+    const int nx = causal ? (nqb + 1) / 2 : nqb;                        // causal: one workgroup per PAIR of query blocks (longest + shortest)
+    dim3 grid((unsigned)((int64_t)nx * H * B)), block(NT);
+#define D3D_FA2(BF, HDV, CA) hipLaunchKernelGGL((k_flash_attn32<BF, HDV, CA>), grid, block, 0, s, q, o, S, H, row_stride, batch_stride, q_off, k_off, v_off, sl2, \
+                                                seq_len, cu_seqlens, nqb, window, nx, B)
+    if (dtype == 0) {
+        if (head_dim == 96) { if (causal) D3D_FA2(true, 96, true); else D3D_FA2(true, 96, false); }
+        else { if (causal) D3D_FA2(true, 64, true); else D3D_FA2(true, 64, false); }
+    } else {
+        if (head_dim == 96) { if (causal) D3D_FA2(false, 96, true); else D3D_FA2(false, 96, false); }
+        else { if (causal) D3D_FA2(false, 64, true); else D3D_FA2(false, 64, false); }
+    }
+#undef D3D_FA2
+    D3D_LAUNCH_CHECK();
+}
+
+}  // extern "C"

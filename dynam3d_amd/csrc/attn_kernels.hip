@@ -559,7 +559,8 @@ k_decode_attn(const uint16_t* __restrict__ qkv_new /* (B, 3H, HD): this step's r
         __hip_atomic_store(mine + HD, jb > ja ? m : -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(mine + HD + 1, jb > ja ? lsum_wg : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                  // every wave's stores are acknowledged ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // every wave's write-through stores are acknowledged (the workgroup-
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                  // scope fence alone emits no vmcnt wait on gfx950) ...
     __syncthreads();                                                        // ... before the ticket is taken
     __shared__ unsigned ticket;
     if (tid == 0) ticket = __hip_atomic_fetch_add(counters + b * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

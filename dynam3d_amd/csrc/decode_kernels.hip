@@ -110,6 +110,10 @@ __device__ __forceinline__ void issue_w(u32x4 (&wb)[32], const uint16_t* __restr
 constexpr int BAR_ERR = 1024;             // flags[0 .. grid): arrival epochs; flags[BAR_ERR]: sticky error flag
 
 __device__ __forceinline__ void bar_arrive(unsigned* flags, unsigned epoch) {
+    // A workgroup-scope release fence emits NO vmcnt wait on gfx950 (checked in the ISA: the write-through stores were followed directly
+    // by s_barrier and the flag store), so the epoch could become visible before this wave's sc1 stores had been acknowledged and a
+    // workgroup on another XCD could read stale activations behind bar_wait: every wave drains its own stores explicitly.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

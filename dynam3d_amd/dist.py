@@ -88,10 +88,22 @@ def all_reduce_gradients(params, bucket_bytes: int = 64 << 20, average: bool = T
     """Data-parallel gradient reduction (DDP's role, PRE-TR:356-360, 512): the gradients of `params` (those that have one) are
     packed into float32 buckets of ~`bucket_bytes`, each bucket is ONE all_reduce (SUM), divided by the world size and scattered
     back into `.grad` in place.  `nan_to_zero` applies the reference's per-parameter NaN scrub (PRE-TR:513-515) after the
-    reduction.  Parameters whose grad is None on this rank are treated as zero so that every rank issues the same collectives
-    (the reference's `* 0.` terms exist for the same reason, PRE-FF:1340).  Returns the number of collectives issued."""
+    reduction.  Parameters whose grad is None on this rank contribute zeros so that every rank issues the same collectives
+    (the reference's `* 0.` terms exist for the same reason, PRE-FF:1340) -- but a parameter that has NO gradient on ANY rank
+    keeps `.grad = None` (one extra all_reduce of a has-grad mask): the optimizer then skips it, as it does under the
+    reference's DDP; materialising zeros would let AdamW decay and update moments of parameters the step did not touch.
+    Returns the number of collectives issued."""
     params = [p for p in params if p.requires_grad]
     world = dist.get_world_size() if dist.is_initialized() else 1
+    has = None
+    if params and world > 1:
+        has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=params[0].device)
+        dist.all_reduce(has, op=dist.ReduceOp.SUM)
+        has = (has > 0).tolist()
+    elif params:
+        has = [p.grad is not None for p in params]
+    if has is not None:
+        params = [p for p, h in zip(params, has) if h]
     n_coll = 0
     if not params:
         return n_coll
@@ -102,7 +114,15 @@ def all_reduce_gradients(params, bucket_bytes: int = 64 << 20, average: bool = T
         if not bucket:
             return
         dev = bucket[0].device
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
+        flat = torch.empty(sum(p.numel() for p in bucket), dtype=torch.float32, device=dev)      # ONE float32 staging buffer per bucket
+        o = 0
+        for p in bucket:
+            n = p.numel()
+            if p.grad is None:
+                flat[o:o + n].zero_()
+            else:
+                flat[o:o + n].copy_(p.grad.reshape(-1))
+            o += n
         if world > 1:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             n_coll += 1

@@ -30,19 +30,23 @@ def _stream():
 class F32Ops:
     def __init__(self):
         self.lib = _lib.load()
-        self._padded: Dict[int, torch.Tensor] = {}
+        self._padded: Dict[tuple, torch.Tensor] = {}
 
     def prep_weight(self, w: torch.Tensor) -> torch.Tensor:
         """(N, K) float32 contiguous; K zero-padded to a multiple of 16 for the MFMA kernel (cached per tensor)."""
         N, K = w.shape
         if K % 16 == 0 or K <= 8 or N <= 8:
             return w
+        # keyed on the storage AND its version counter: an in-place update (optimizer step, load_state_dict) or a new tensor allocated
+        # at a freed address must not be served another tensor's / an older padded copy; one entry per address, so updates replace
         key = w.data_ptr()
-        if key not in self._padded:
+        tag = (w._version, N, K)
+        hit = self._padded.get(key)
+        if hit is None or hit[0] != tag:
             wp = torch.zeros((N, (K + 15) // 16 * 16), dtype=torch.float32, device=w.device)
-            wp[:, :K] = w
-            self._padded[key] = wp
-        return self._padded[key]
+            wp[:, :K] = w.detach()
+            hit = self._padded[key] = (tag, wp)
+        return hit[1]
 
     def linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, act: Optional[str] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         """y = act(x w^T + b) [+ residual]; x (M, K) float32 (row stride % 4 == 0), w (N, K)."""

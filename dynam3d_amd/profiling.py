@@ -11,10 +11,12 @@ import torch
 class EventTimer:
     def __init__(self):
         self.pairs = defaultdict(list)
+        self.meta = defaultdict(list)
         self.enabled = False
 
     @contextmanager
-    def range(self, name: str):
+    def range(self, name: str, **meta):
+        """`meta`: numbers that belong to THIS launch (e.g. rows=real tokens), kept beside its event pair (`records`)."""
         if not self.enabled:
             yield
             return
@@ -23,6 +25,8 @@ class EventTimer:
         yield
         b.record()
         self.pairs[name].append((a, b))
+        if meta:
+            self.meta[name].append(meta)
 
     def summary(self):
         """name -> (count, mean ms); call after torch.cuda.synchronize()."""
@@ -32,8 +36,15 @@ class EventTimer:
             out[k] = (len(ts), sum(ts) / max(len(ts), 1))
         return out
 
+    def records(self, name: str):
+        """[(ms, meta dict)] per timed launch of `name`, in issue order; call after torch.cuda.synchronize()."""
+        ts = [a.elapsed_time(b) for a, b in self.pairs.get(name, [])]
+        ms = self.meta.get(name, [])
+        return [(t, ms[i] if i < len(ms) else {}) for i, t in enumerate(ts)]
+
     def reset(self):
         self.pairs.clear()
+        self.meta.clear()
 
 
 TIMER = EventTimer()

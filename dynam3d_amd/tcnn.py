@@ -36,6 +36,10 @@ _lib.register("d3d_lrelu_bwd", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C
 
 OUTPUT_PAD = 16      # tinycudann: padded output width = next multiple of the tensor-core width
 GEMM_PAD = 128       # d3d_gemm_nt: N % 128 == 0
+LOSS_SCALE = 128.0   # tinycudann's PyTorch binding multiplies dL/dy by `loss_scale` (128 for fp16 networks) before the fp16 backward and
+                     # divides the float32 gradients by it; the reference trains under autocast WITHOUT a GradScaler (PRE-TR:501-512) and
+                     # relies on exactly that: the mean-reduced cosine / InfoNCE losses give per-element gradients of 1e-5 .. 1e-7, which
+                     # are subnormal or zero in fp16
 
 
 def _stream():
@@ -60,13 +64,14 @@ class _MlpFunction(torch.autograd.Function):
             act = net.out_act if l == L - 1 else net.act
             h = hd.gemm(h, w, None, None, "lrelu" if act == "LeakyReLU" else "none")
             acts.append(h)
-        ctx.net, ctx.acts = net, acts
+        ctx.net = net
+        ctx.save_for_backward(*acts)                                 # (saved tensors: autograd detects `params` / activations modified in between)
         ctx.x_dtype = x.dtype
         return h[:, : net.n_output_dims]
 
     @staticmethod
     def backward(ctx, dy):
-        net, acts, hd = ctx.net, ctx.acts, ctx.net.hd
+        net, acts, hd = ctx.net, list(ctx.saved_tensors), ctx.net.hd
         lib = hd.lib
         ws_t = net._layer_weights_t()                                # fp16 [in, out_pad128] per layer = W^T, the NT operand of dz W
         M = acts[0].shape[0]
@@ -74,23 +79,24 @@ class _MlpFunction(torch.autograd.Function):
         L = len(ws_t)
         n_last = ws_t[-1].shape[1]
         dz = torch.zeros((M, n_last), dtype=torch.float16, device=net.device)
-        dz[:, : net.n_output_dims] = dy.to(torch.float16)
+        dz[:, : net.n_output_dims] = (dy.float() * LOSS_SCALE).to(torch.float16)      # scaled into fp16's range (see LOSS_SCALE)
         if net.out_act == "LeakyReLU":
             _lib.check(lib.d3d_lrelu_bwd(_p(dz), _p(acts[-1]), _p(dz), dz.numel(), 1, _stream()))
         grads: List[torch.Tensor] = [None] * L
         for l in range(L - 1, -1, -1):
             h_prev = acts[l]                                          # input of layer l (= x for l = 0)
             N, K = dz.shape[1], h_prev.shape[1]
-            dz_t = torch.empty((N, Mp), dtype=torch.float16, device=net.device)
-            h_t = torch.empty((K, Mp), dtype=torch.float16, device=net.device)
+            Kp = (K + GEMM_PAD - 1) // GEMM_PAD * GEMM_PAD           # h^T is the GEMM's [N, K] operand: rows padded to the tile (a 64- or
+            dz_t = torch.empty((N, Mp), dtype=torch.float16, device=net.device)      # 192-wide input layer would otherwise fail here)
+            h_t = torch.empty((K, Mp), dtype=torch.float16, device=net.device) if Kp == K else torch.zeros((Kp, Mp), dtype=torch.float16, device=net.device)
             _lib.check(lib.d3d_transpose_pad16(_p(dz), _p(dz_t), M, N, dz.stride(0), Mp, _stream()))
             _lib.check(lib.d3d_transpose_pad16(_p(h_prev), _p(h_t), M, K, h_prev.stride(0), Mp, _stream()))
-            grads[l] = hd.gemm(dz_t, h_t, None, None, "none")        # dW_l (N, K) = dz^T h_prev
+            grads[l] = hd.gemm(dz_t, h_t, None, None, "none")[:, :K]  # dW_l (N, K) = dz^T h_prev
             if l > 0:
                 dz = hd.gemm(dz, ws_t[l], None, h_prev, "lrelu_bwd") if net.act == "LeakyReLU" else hd.gemm(dz, ws_t[l], None, None, "none")
             elif ctx.needs_input_grad[0]:
-                dz = hd.gemm(dz, ws_t[0], None, None, "none")        # dx
-        dx = dz.to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+                dz = hd.gemm(dz, ws_t[0], None, None, "none")[:, : net.n_input_dims]        # dx
+        dx = (dz.float() / LOSS_SCALE).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
         dparams = net._flat_grad(grads) if ctx.needs_input_grad[1] else None
         return dx, dparams, None
 
@@ -174,7 +180,10 @@ class Network(torch.nn.Module):
             w16 = torch.zeros((self._rows_gemm[i], self.dims[i]), dtype=torch.float16, device=self.device)
             w16[: w.shape[0]] = w.to(torch.float16)
             ws.append(w16)
-            ws_t.append(w16.t().contiguous())
+            wt = w16.t().contiguous()                                # [in, out_pad]: the NT operand of dz W_l (N = in -> rows padded to the tile)
+            if wt.shape[0] % GEMM_PAD:
+                wt = torch.cat([wt, torch.zeros((GEMM_PAD - wt.shape[0] % GEMM_PAD, wt.shape[1]), dtype=wt.dtype, device=wt.device)])
+            ws_t.append(wt)
         self._w, self._w_t, self._cache_version = ws, ws_t, ver
 
     def _layer_weights(self):
@@ -194,7 +203,7 @@ class Network(torch.nn.Module):
         o = 0
         for i, r in enumerate(self._rows_flat):
             n = r * self.dims[i]
-            g = grads[i][: self.dims[i + 1]].float()
+            g = grads[i][: self.dims[i + 1]].float() / LOSS_SCALE
             out[o:o + g.numel()] = g.reshape(-1)
             o += n
         return out

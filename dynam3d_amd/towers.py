@@ -144,17 +144,22 @@ class _VitTrunk:
         """pixels (B,3,336,336) normalised float32 -> (B,577,width) after patch embedding, cls/pos and ln_pre (clip/model.py:222-228)."""
         return D.vit_embed(pixels.float(), self.patch_w, self.cls, self.pos, self.ln_pre[0], self.ln_pre[1], self.cfg.patch, 1e-5)
 
-    def run_blocks(self, x: torch.Tensor, n_layers: int) -> torch.Tensor:
-        c = self.cfg
+    def block(self, i: int, x: torch.Tensor) -> torch.Tensor:
+        """Residual block i on x (B, L, W) (clip/model.py:166-187 `ResidualAttentionBlock` == HF `CLIPEncoderLayer`); also the entry point of
+        the per-layer teacher-forced parity tests."""
+        c, blk = self.cfg, self.blocks[i]
         B, L, W = x.shape
-        for blk in self.blocks[:n_layers]:
-            h = D.layer_norm(x, blk["ln1_w"], blk["ln1_b"], 1e-5)
-            qkv = D.linear(h.view(B * L, W), blk["qkv_w"], blk["qkv_b"]).view(B, L, 3 * c.heads, W // c.heads)
-            a = D.attention_qkv(qkv, c.heads, causal=False)                                    # (B,L,H,hd)
-            x = D.linear(a.reshape(B * L, W), blk["out_w"], blk["out_b"], residual=x.view(B * L, W)).view(B, L, W)
-            h = D.layer_norm(x, blk["ln2_w"], blk["ln2_b"], 1e-5)
-            h = D.linear(h.view(B * L, W), blk["fc1_w"], blk["fc1_b"], act="quick_gelu")
-            x = D.linear(h, blk["fc2_w"], blk["fc2_b"], residual=x.view(B * L, W)).view(B, L, W)
+        h = D.layer_norm(x, blk["ln1_w"], blk["ln1_b"], 1e-5)
+        qkv = D.linear(h.view(B * L, W), blk["qkv_w"], blk["qkv_b"]).view(B, L, 3 * c.heads, W // c.heads)
+        a = D.attention_qkv(qkv, c.heads, causal=False)                                    # (B,L,H,hd)
+        x = D.linear(a.reshape(B * L, W), blk["out_w"], blk["out_b"], residual=x.view(B * L, W)).view(B, L, W)
+        h = D.layer_norm(x, blk["ln2_w"], blk["ln2_b"], 1e-5)
+        h = D.linear(h.view(B * L, W), blk["fc1_w"], blk["fc1_b"], act="quick_gelu")
+        return D.linear(h, blk["fc2_w"], blk["fc2_b"], residual=x.view(B * L, W)).view(B, L, W)
+
+    def run_blocks(self, x: torch.Tensor, n_layers: int) -> torch.Tensor:
+        for i in range(n_layers):
+            x = self.block(i, x)
         return x
 
 
@@ -253,13 +258,13 @@ class Phi3Decoder:
     SLIDING_WINDOW = 2047         # Phi-3-mini-4k-instruct config.json: every layer attends to the last 2047 keys only
 
     def _check_lengths(self, lens, max_new_tokens: int = 0):
-        """Prompts the kernels do not model: longer than Phi-3-mini's sliding attention window (HF masks keys further back than 2047;
-        here attention is full causal, so results would silently differ) or than the rotary table.  The reference's prompts are
-        2 + 576 + Ni + Nz + text ~ 0.8-1.1 k tokens."""
+        """Prompts the kernels do not model.  The PREFILL masks Phi-3-mini's sliding attention window (every layer attends to the last
+        2047 keys only) inside the flash kernel (`d3d_flash_attention_v2(window=...)`); the KV-cache decode kernel does not, so generation
+        is limited to prompt + new tokens <= 2047.  The reference's prompts are 2 + 576 + Ni + Nz + text ~ 0.8-1.4 k tokens."""
         longest = max(lens) + max_new_tokens
-        if longest > self.SLIDING_WINDOW:
+        if max_new_tokens and longest > self.SLIDING_WINDOW:
             raise ValueError(f"prompt of {max(lens)} tokens (+{max_new_tokens} generated) exceeds Phi-3-mini's sliding window of {self.SLIDING_WINDOW} keys, "
-                             "which this implementation does not model")
+                             "which the KV-cache decode kernel does not model")
         if longest > self.cfg.max_pos or longest > self.MAX_DECODE_KEYS:
             raise ValueError(f"sequence of {longest} tokens exceeds max_position_embeddings = {self.cfg.max_pos}")
 
@@ -300,14 +305,8 @@ class Phi3Decoder:
             torch.cat([r.to(self.dtype) for r in rows], 0, out=x[:T])
         return self.prefill_logits_packed(x, lens)
 
-    @torch.no_grad()
-    def prefill_logits_packed(self, x: torch.Tensor, lens, keep_kv: Optional[list] = None) -> torch.Tensor:
-        """x (Tp, hidden) in the LM's dtype: the B prompts back to back (lens[b] rows each), zero rows up to Tp (a multiple
-        of 256).  -> logits (B, vocab) float32 at each prompt's last position.  `keep_kv`: a list that receives every layer's
-        fused-QKV buffer after RoPE -- the prompt part of the KV cache, read in place by `generate_packed`."""
-        c = self.cfg
-        B, Tp = len(lens), x.shape[0]
-        self._check_lengths(lens)
+    def packed_context(self, lens, Tp: int):
+        """Per-call tables of the packed prefill: sequence offsets (device + host), per-row rotary positions, cos / sin, last rows."""
         cu_h = [0]
         for n in lens:
             cu_h.append(cu_h[-1] + n)
@@ -318,36 +317,59 @@ class Phi3Decoder:
         pos = pos_h.to(self.device, non_blocking=True)
         max_len = max(lens)
         cos, sin = self._rope(max_len)
-        Ht = c.heads + 2 * c.kv_heads
-        last_rows = (cu[1:] - 1).long()
-        for li, L in enumerate(self.layers):
-            h = D.rms_norm(x, L["n1"], c.rms_eps)
-            qkv = D.linear(h, L["qkv_w"], None)
-            D.rope_packed_(qkv, c.heads + c.kv_heads, c.head_dim, cos, sin, pos)
-            if keep_kv is not None:
-                keep_kv.append(qkv)
-            a = D.attention_packed(qkv.view(Tp, Ht, c.head_dim), c.heads, True, cu, B, max_len, n_valid=cu_h[-1])
-            a = a.view(Tp, c.heads * c.head_dim)
-            if li == len(self.layers) - 1 and self.PRUNE_LAST_LAYER:
-                # Behind the last layer's attention every operation is row-wise and only each prompt's LAST row is read (the logits of the
-                # next token; the layer's keys / values -- all rows -- are already in `qkv`): o_proj, the MLP, the final norm and the
-                # lm_head run on B rows instead of Tp.  Same arithmetic per row, 1/32 of the stack's o_proj + MLP GEMM time saved.
-                a, x = a[last_rows].contiguous(), x[last_rows].contiguous()
-            x = D.linear(a, L["o_w"], None, residual=x)
-            h = D.rms_norm(x, L["n2"], c.rms_eps)
-            if h.shape[0] == Tp:
-                with TIMER.range("phi3.gate_up_proj"):                      # (bench.py's roofline launch: the full-row GEMMs only)
-                    act = D.linear_swiglu(h, L["gu_w"], self.interleave_gu)
-                with TIMER.range("phi3.event_pair_overhead"):               # an EMPTY bracket right behind it: what two event records
-                    pass                                                    # cost on this stream at this point (bench.py subtracts it)
-            else:
+        return dict(cu=cu, cu_h=cu_h, pos=pos, cos=cos, sin=sin, max_len=max_len, last_rows=(cu[1:] - 1).long(), B=len(lens), Tp=Tp)
+
+    @torch.no_grad()
+    def layer_packed(self, li: int, x: torch.Tensor, ctx, keep_kv: Optional[list] = None, prune: bool = False) -> torch.Tensor:
+        """One decoder layer over the packed rows x (Tp, hidden) -> (Tp, hidden) (HF `Phi3DecoderLayer.forward`: RMSNorm, fused QKV,
+        rotary, causal attention per sequence, o_proj + residual, RMSNorm, gate_up + SwiGLU, down_proj + residual).  `prune`: behind
+        the attention only each prompt's LAST row is evaluated -> (B, hidden) (see `prefill_logits_packed`).  Also the entry point of
+        the per-layer teacher-forced parity tests (tests/test_gpu_depth_parity.py)."""
+        c, L = self.cfg, self.layers[li]
+        Tp, Ht = x.shape[0], c.heads + 2 * c.kv_heads
+        h = D.rms_norm(x, L["n1"], c.rms_eps)
+        qkv = D.linear(h, L["qkv_w"], None)
+        D.rope_packed_(qkv, c.heads + c.kv_heads, c.head_dim, ctx["cos"], ctx["sin"], ctx["pos"])
+        if keep_kv is not None:
+            keep_kv.append(qkv)
+        a = D.attention_packed(qkv.view(Tp, Ht, c.head_dim), c.heads, True, ctx["cu"], ctx["B"], ctx["max_len"], n_valid=ctx["cu_h"][-1],
+                               window=self.SLIDING_WINDOW if ctx["max_len"] > self.SLIDING_WINDOW else 0)
+        a = a.view(Tp, c.heads * c.head_dim)
+        if prune:
+            a, x = a[ctx["last_rows"]].contiguous(), x[ctx["last_rows"]].contiguous()
+        x = D.linear(a, L["o_w"], None, residual=x)
+        h = D.rms_norm(x, L["n2"], c.rms_eps)
+        if h.shape[0] == Tp:
+            with TIMER.range("phi3.gate_up_proj", rows=ctx["cu_h"][-1]):    # (bench.py's roofline launch: the full-row GEMMs only)
                 act = D.linear_swiglu(h, L["gu_w"], self.interleave_gu)
-            x = D.linear(act, L["down_w"], None, residual=x)
+            with TIMER.range("phi3.event_pair_overhead"):                   # an EMPTY bracket right behind it: what two event records
+                pass                                                        # cost on this stream at this point (bench.py subtracts it)
+        else:
+            act = D.linear_swiglu(h, L["gu_w"], self.interleave_gu)
+        return D.linear(act, L["down_w"], None, residual=x)
+
+    @torch.no_grad()
+    def final_logits(self, last: torch.Tensor) -> torch.Tensor:
+        """(B, hidden) last-position rows -> (B, vocab) float32: final RMSNorm + lm_head."""
+        return D.linear(D.rms_norm(last, self.norm_w, self.cfg.rms_eps), self.lm_head_w, None).float()
+
+    @torch.no_grad()
+    def prefill_logits_packed(self, x: torch.Tensor, lens, keep_kv: Optional[list] = None) -> torch.Tensor:
+        """x (Tp, hidden) in the LM's dtype: the B prompts back to back (lens[b] rows each), zero rows up to Tp (a multiple
+        of 256).  -> logits (B, vocab) float32 at each prompt's last position.  `keep_kv`: a list that receives every layer's
+        fused-QKV buffer after RoPE -- the prompt part of the KV cache, read in place by `generate_packed`."""
+        B, Tp = len(lens), x.shape[0]
+        self._check_lengths(lens)
+        ctx = self.packed_context(lens, Tp)
+        n = len(self.layers)
+        for li in range(n):
+            # Behind the last layer's attention every operation is row-wise and only each prompt's LAST row is read (the logits of the
+            # next token; the layer's keys / values -- all rows -- are already in `qkv`): o_proj, the MLP, the final norm and the
+            # lm_head run on B rows instead of Tp.  Same arithmetic per row, 1/32 of the stack's o_proj + MLP GEMM time saved.
+            x = self.layer_packed(li, x, ctx, keep_kv, prune=(li == n - 1 and self.PRUNE_LAST_LAYER))
         self.last_packed_rows = Tp
-        self._last_cu = cu
-        last = x if x.shape[0] == B else x[last_rows]
-        last = D.rms_norm(last, self.norm_w, c.rms_eps)
-        return D.linear(last, self.lm_head_w, None).float()
+        self._last_cu = ctx["cu"]
+        return self.final_logits(x if x.shape[0] == B else x[ctx["last_rows"]])
 
     @torch.no_grad()
     def generate_packed(self, x: torch.Tensor, lens, max_new_tokens: int = 20, end_id: Optional[int] = None, forced=None,

@@ -339,6 +339,15 @@ int32_t d3d_flash_attention(const void* qkv_d, void* out_d, void* vt_scratch_d /
                             int32_t head_dim, int64_t row_stride,
                             int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
                             const int32_t* cu_seqlens_d /* optional (B+1): packed variable-length batch */, int32_t dtype, void* stream);
+/* Second-generation kernel behind the same contract (csrc/attn2_kernels.hip: 32x32x16 MFMA tiles, one query column per lane pair,
+ * K/V double-buffered in LDS with one barrier per key tile, masked 32-key blocks of diagonal tiles skipped; the default of the Python
+ * host since round 3, d3d_flash_attention stays as the A/B baseline).  `window` > 0 (causal only): a query attends to its last `window`
+ * keys, itself included -- HF's sliding-window mask (Phi-3-mini-4k: 2047; transformers 4.46 modeling_phi3.py
+ * `_prepare_4d_causal_attention_mask_with_cache_position`: key <= query - window is masked); 0 = no window. */
+int32_t d3d_flash_attention_v2(const void* qkv_d, void* out_d, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride,
+                               int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
+                               const int32_t* cu_seqlens_d /* optional (B+1): packed variable-length batch */, int32_t window, int32_t dtype,
+                               void* stream);
 /* self-attention inside packed variable-length token sets (set encoders VLN-FF:134-155): float32, head_dim 64.
  * qkv (T, 3*H*64) = [q|k|v]; set g = tokens [set_off[g], set_off[g+1]); q_rows > 0 restricts the queries to the
  * first q_rows rows of every set (1 = CLS only).  out (T, H*64); rows that are not queried are left untouched. */

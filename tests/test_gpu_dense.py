@@ -256,12 +256,17 @@ def test_set_attention_varlen(hd):
             assert float(cls[off[g] + 1:off[g + 1]].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("v_tr", [True, False])
+ATTN_VARIANTS = {"v2": (True, True), "v1_tr": (False, True), "v1_workspace": (False, False)}      # (ATTN_V2, V_TR)
+
+
+@pytest.mark.parametrize("variant", list(ATTN_VARIANTS))
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 4e-3), (torch.float16, 6e-4)])
-def test_flash_attention_vs_fp32_reference(hd, dt, tol, v_tr, monkeypatch):
-    """d3d_flash_attention (head_dim 64/96, causal/full, ragged S, masked tail) vs float32 SDPA on the same 16-bit inputs.
-    v_tr: V transposed by ds_read_b64_tr_b16 inside the kernel (the default) / the pre-transposed V^T workspace variant."""
-    monkeypatch.setattr(type(hd), "V_TR", v_tr)
+def test_flash_attention_vs_fp32_reference(hd, dt, tol, variant, monkeypatch):
+    """d3d_flash_attention_v2 / d3d_flash_attention (head_dim 64/96, causal/full, ragged S, masked tail) vs float32 SDPA on the same 16-bit
+    inputs.  Variants: v2 = the 32x32x16 kernel (default); v1_tr / v1_workspace = round 1/2's kernel with V transposed by
+    ds_read_b64_tr_b16 / through a pre-transposed V^T workspace."""
+    monkeypatch.setattr(type(hd), "ATTN_V2", ATTN_VARIANTS[variant][0])
+    monkeypatch.setattr(type(hd), "V_TR", ATTN_VARIANTS[variant][1])
     torch.manual_seed(4)
     for (B, H, S, d, causal) in [(2, 3, 577, 64, False), (2, 4, 900, 96, True), (1, 2, 130, 96, True), (3, 2, 64, 64, True), (1, 1, 1, 96, True), (2, 2, 333, 96, False)]:
         qkv = (torch.randn(B, S, 3 * H, d, device="cuda") * 1.5).to(dt)
@@ -280,14 +285,15 @@ def test_flash_attention_vs_fp32_reference(hd, dt, tol, v_tr, monkeypatch):
     assert rel(hd.attention_qkv(qkv, H, True).float(), ref) < tol
 
 
-@pytest.mark.parametrize("v_tr", [True, False])
+@pytest.mark.parametrize("variant", list(ATTN_VARIANTS))
 @pytest.mark.parametrize("causal", [True, False])
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 6e-3), (torch.float16, 1e-3)])
-def test_flash_attention_packed_ragged(hd, dt, tol, causal, v_tr, monkeypatch):
+def test_flash_attention_packed_ragged(hd, dt, tol, causal, variant, monkeypatch):
     """Packed variable-length batch (cu_seqlens): sequences of 1 token, below / at / just above a 128-row query block and a
     64-key tile, odd and even block counts (the causal kernel pairs the longest block of a sequence with its shortest), padding
     rows after the last sequence.  Reference: fp32 softmax attention per sequence.  Tolerance = 16-bit output rounding + 16-bit P."""
-    monkeypatch.setattr(type(hd), "V_TR", v_tr)
+    monkeypatch.setattr(type(hd), "ATTN_V2", ATTN_VARIANTS[variant][0])
+    monkeypatch.setattr(type(hd), "V_TR", ATTN_VARIANTS[variant][1])
     torch.manual_seed(5)
     H, d = 4, 96
     lens = [1, 63, 128, 129, 200, 385, 640, 705]
@@ -304,6 +310,36 @@ def test_flash_attention_packed_ragged(hd, dt, tol, causal, v_tr, monkeypatch):
         assert rel(out[o:o + n], ref) < tol, (n, rel(out[o:o + n], ref))
         o += n
     assert float(out[T:].abs().max()) == 0.0                     # padding rows untouched
+
+
+def test_flash_attention_sliding_window(hd):
+    """The v2 kernel's sliding window (HF Phi-3-mini-4k: a query attends to its last `window` keys, itself included): packed ragged
+    prompts longer than the window and a dense batch, windows that cut inside a tile / at a tile edge / before the first query block,
+    against an explicitly masked float32 softmax."""
+    torch.manual_seed(8)
+    H, d = 2, 96
+    for dt, tol in ((torch.bfloat16, 6e-3), (torch.float16, 1e-3)):
+        for window in (1, 50, 64, 257, 300):
+            lens = [40, 333, 700]
+            T = sum(lens)
+            qkv = (torch.randn((T + 255) // 256 * 256, 3 * H, d, device="cuda") * 0.8).to(dt)
+            cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+            out = hd.attention_packed(qkv, H, True, cu, len(lens), max(lens), window=window).float()
+            o = 0
+            for n in lens:
+                x = qkv[o:o + n].float()
+                q, k, v = x[:, :H].transpose(0, 1), x[:, H:2 * H].transpose(0, 1), x[:, 2 * H:].transpose(0, 1)      # (H,n,d)
+                i = torch.arange(n, device="cuda")
+                ok = (i[None, :] <= i[:, None]) & (i[None, :] > i[:, None] - window)
+                ref = F.scaled_dot_product_attention(q[None], k[None], v[None], attn_mask=ok[None, None])[0].transpose(0, 1)
+                assert rel(out[o:o + n], ref) < tol, (window, n, rel(out[o:o + n], ref))
+                o += n
+        qkv = (torch.randn(2, 400, 3 * H, 64, device="cuda")).to(dt)
+        q, k, v = (qkv[:, :, i * H:(i + 1) * H].transpose(1, 2).float() for i in range(3))
+        i = torch.arange(400, device="cuda")
+        ok = (i[None, :] <= i[:, None]) & (i[None, :] > i[:, None] - 130)
+        ref = F.scaled_dot_product_attention(q, k, v, attn_mask=ok[None, None]).transpose(1, 2)
+        assert rel(hd.attention_qkv(qkv, H, True, window=130).float(), ref) < tol
 
 
 @pytest.mark.parametrize("split", [None, "2"])

@@ -81,3 +81,28 @@ def test_tcnn_forward_backward_on_hip_matches_autograd_restatement(out_act, n_ou
     ws2 = [w.detach().float().cpu() for w in net.layers_from_flat(net.params)]
     assert rel(y2.float().cpu(), NN.tcnn_mlp(x.half().float(), [w.half().float() for w in ws2], "LeakyReLU", out_act, store=torch.float16)) < 1e-3
     assert not torch.equal(y2, y.detach())
+
+
+@pytest.mark.gpu
+def test_tcnn_backward_keeps_tiny_gradients_and_odd_input_widths():
+    """dL/dy ~ 1e-6 (the mean-reduced losses of the reference's trainer, which runs WITHOUT a GradScaler and relies on tinycudann's
+    internal loss_scale = 128): un-scaled, such gradients are subnormal / zero in fp16.  And a 192-wide input layer (n_input_dims
+    % 128 != 0) must survive the backward GEMMs, whose N is the input width."""
+    from dynam3d_amd import tcnn
+    from oracle import nnref as NN
+    torch.manual_seed(6)
+    for n_in, dy_scale, tol in ((768, 1e-6, 3e-2), (192, 0.1, 5e-3)):
+        net = tcnn.Network(n_in, 768, CFG("None"), device="cuda", seed=12)
+        ws = [w.detach().float().cpu() for w in net.layers_from_flat(net.params)]
+        x = torch.randn(300, n_in) * 0.8
+        dy = torch.randn(300, 768) * dy_scale
+        xr = x.half().float().requires_grad_(True)
+        wr = [w.half().float().requires_grad_(True) for w in ws]
+        NN.tcnn_mlp(xr, wr, "LeakyReLU", "None", store=torch.float16).backward(dy)
+        xg = x.cuda().requires_grad_(True)
+        net(xg).backward(dy.cuda())
+        rel = lambda a, b: float((a.detach().double() - b.detach().double()).norm() / b.detach().double().norm())
+        gl = net.layers_from_flat(net.params.grad.detach().cpu())
+        errs = dict(dx=rel(xg.grad.float().cpu(), xr.grad), **{f"dW{l}": rel(g, w.grad) for l, (g, w) in enumerate(zip(gl, wr))})
+        print("tcnn backward", n_in, dy_scale, {k: f"{v:.2e}" for k, v in errs.items()})
+        assert all(v < tol for v in errs.values()), errs
