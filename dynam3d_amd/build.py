@@ -28,6 +28,7 @@ HIP_SOURCES = [
     ("attn2_kernels.hip", ["-ffp-contract=fast"]),
     ("decode_kernels.hip", ["-ffp-contract=fast"]),
     ("render_kernels.hip", ["-ffp-contract=off"]),
+    ("mlp_kernels.hip", ["-ffp-contract=fast"]),
 ]
 CPP_SOURCES = ["ff_state.cpp", "d3d_error.cpp", "phi3_decode.cpp", "mlp_forward.cpp"]
 HOST_CPP_SOURCES = ["ff_state.cpp", "d3d_error.cpp"]      # the CPU-only bookkeeping library (no device entry points)

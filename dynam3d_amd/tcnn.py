@@ -31,6 +31,8 @@ from .hip_dense import HipDense
 
 _lib.register("d3d_mlp768_forward", [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
+_lib.register("d3d_mlp_fused", [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int32, C.c_void_p])
 _lib.register("d3d_transpose_pad16", [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p])
 _lib.register("d3d_lrelu_bwd", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p])
 
@@ -40,6 +42,34 @@ LOSS_SCALE = 128.0   # tinycudann's PyTorch binding multiplies dL/dy by `loss_sc
                      # divides the float32 gradients by it; the reference trains under autocast WITHOUT a GradScaler (PRE-TR:501-512) and
                      # relies on exactly that: the mean-reduced cosine / InfoNCE losses give per-element gradients of 1e-5 .. 1e-7, which
                      # are subnormal or zero in fp16
+
+
+FUSED_MAX_WIDTH = 896       # csrc/mlp_kernels.hip: the 64-row activation slab lives in LDS
+import os as _os
+FUSED = _os.environ.get("D3D_MLP_FUSED", "0") == "1"     # True: one d3d_mlp_fused launch per network (forward and the backward's data-gradient
+                                                         # chain); default: one d3d_gemm_nt launch per layer -- measured 2.5-3x FASTER (119 vs 37 us
+                                                         # at 1 152 rows: csrc/mlp_kernels.hip header).  Both are bit-identical and both are tested.
+
+
+def fused_ok(widths) -> bool:
+    return FUSED and len(widths) - 1 <= 4 and all(w <= FUSED_MAX_WIDTH and w % 16 == 0 for w in widths) and all(w % 32 == 0 for w in widths[:-1])
+
+
+def mlp_fused(lib, x, weights, modes, aux=None, save=None):
+    """One launch of d3d_mlp_fused over the chain `weights` ([out_l, in_l] fp16 each).  modes[l]: 0 / 1 (LeakyReLU) / 2 (x LeakyReLU'(aux[l])).
+    save[l] True -> layer l's output is also written to HBM and returned (the last layer's always is).  Returns the list of saved outputs."""
+    n, L = x.shape[0], len(weights)
+    widths = [x.shape[1]] + [int(w.shape[0]) for w in weights]
+    save = [bool(save[l]) if save is not None else False for l in range(L)]
+    save[-1] = True
+    outs = [torch.empty((n, widths[l + 1]), dtype=x.dtype, device=x.device) if save[l] else None for l in range(L)]
+    aux = aux or [None] * L
+    i32a = lambda v: (C.c_int32 * len(v))(*v)
+    i64a = lambda v: (C.c_int64 * len(v))(*v)
+    pa = lambda ts: (C.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+    _lib.check(lib.d3d_mlp_fused(x.data_ptr(), x.stride(0), n, L, i32a(widths), pa(weights), i32a(modes), pa(aux), i64a([0 if t is None else t.stride(0) for t in aux]),
+                                 pa(outs), i64a([0 if t is None else t.stride(0) for t in outs]), 0 if x.dtype == torch.bfloat16 else 1, _stream()))
+    return outs
 
 
 def _stream():
@@ -60,10 +90,16 @@ class _MlpFunction(torch.autograd.Function):
         h = x.detach().to(net.device, torch.float16).contiguous()
         acts = [h]
         L = len(ws)
-        for l, w in enumerate(ws):
-            act = net.out_act if l == L - 1 else net.act
-            h = hd.gemm(h, w, None, None, "lrelu" if act == "LeakyReLU" else "none")
-            acts.append(h)
+        if fused_ok([h.shape[1]] + [int(w.shape[0]) for w in ws]):
+            # ONE launch: the slab of activations stays in LDS across the layers, every layer's output is also saved for the backward pass
+            modes = [1 if (net.out_act if l == L - 1 else net.act) == "LeakyReLU" else 0 for l in range(L)]
+            acts += mlp_fused(hd.lib, h, ws, modes, save=[True] * L)
+            h = acts[-1]
+        else:
+            for l, w in enumerate(ws):
+                act = net.out_act if l == L - 1 else net.act
+                h = hd.gemm(h, w, None, None, "lrelu" if act == "LeakyReLU" else "none")
+                acts.append(h)
         ctx.net = net
         ctx.save_for_backward(*acts)                                 # (saved tensors: autograd detects `params` / activations modified in between)
         ctx.x_dtype = x.dtype
@@ -83,7 +119,19 @@ class _MlpFunction(torch.autograd.Function):
         if net.out_act == "LeakyReLU":
             _lib.check(lib.d3d_lrelu_bwd(_p(dz), _p(acts[-1]), _p(dz), dz.numel(), 1, _stream()))
         grads: List[torch.Tensor] = [None] * L
+        # data gradients dz_l (the gradient at layer l's OUTPUT): dz_{l-1} = (dz_l W_l) * act'(h_{l-1}).  Fused: the whole chain in one
+        # launch (weights = the transposed matrices, mode 2 takes the slope from the saved activation), every dz_l stored for dW_l below.
+        dzs = {L - 1: dz}
+        need_dx = bool(ctx.needs_input_grad[0])
+        chain = list(range(L - 1, 0 if need_dx else 0, -1)) + ([0] if need_dx else [])
+        fused_bwd = bool(chain) and fused_ok([dz.shape[1]] + [int(ws_t[l].shape[0]) for l in chain])
+        if fused_bwd:
+            modes = [(2 if net.act == "LeakyReLU" else 0) if l > 0 else 0 for l in chain]
+            outs = mlp_fused(hd.lib, dz, [ws_t[l] for l in chain], modes, aux=[acts[l] if l > 0 else None for l in chain], save=[True] * len(chain))
+            for l, o in zip(chain, outs):
+                dzs[l - 1] = o                                            # (dzs[-1] = dx, padded to the tile)
         for l in range(L - 1, -1, -1):
+            dz = dzs[l] if fused_bwd else dz
             h_prev = acts[l]                                          # input of layer l (= x for l = 0)
             N, K = dz.shape[1], h_prev.shape[1]
             Kp = (K + GEMM_PAD - 1) // GEMM_PAD * GEMM_PAD           # h^T is the GEMM's [N, K] operand: rows padded to the tile (a 64- or
@@ -92,10 +140,14 @@ class _MlpFunction(torch.autograd.Function):
             _lib.check(lib.d3d_transpose_pad16(_p(dz), _p(dz_t), M, N, dz.stride(0), Mp, _stream()))
             _lib.check(lib.d3d_transpose_pad16(_p(h_prev), _p(h_t), M, K, h_prev.stride(0), Mp, _stream()))
             grads[l] = hd.gemm(dz_t, h_t, None, None, "none")[:, :K]  # dW_l (N, K) = dz^T h_prev
+            if fused_bwd:
+                continue
             if l > 0:
                 dz = hd.gemm(dz, ws_t[l], None, h_prev, "lrelu_bwd") if net.act == "LeakyReLU" else hd.gemm(dz, ws_t[l], None, None, "none")
             elif ctx.needs_input_grad[0]:
                 dz = hd.gemm(dz, ws_t[0], None, None, "none")[:, : net.n_input_dims]        # dx
+        if fused_bwd and need_dx:
+            dz = dzs[-1][:, : net.n_input_dims]
         dx = (dz.float() / LOSS_SCALE).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
         dparams = net._flat_grad(grads) if ctx.needs_input_grad[1] else None
         return dx, dparams, None
@@ -216,6 +268,9 @@ class Network(torch.nn.Module):
             return _MlpFunction.apply(x, self.params, self)
         ws = self._layer_weights()
         h = x.detach().to(self.device, torch.float16).contiguous()
+        if fused_ok([h.shape[1]] + [int(w.shape[0]) for w in ws]):
+            modes = [1 if (self.out_act if l == len(ws) - 1 else self.act) == "LeakyReLU" else 0 for l in range(len(ws))]
+            return mlp_fused(self.hd.lib, h, ws, modes)[-1][:, : self.n_output_dims]
         n, nn_, n_pad = h.shape[0], self.dims[1], ws[-1].shape[0]
         y = torch.empty((n, n_pad), dtype=torch.float16, device=self.device)
         sa, sb = (torch.empty((n, nn_), dtype=torch.float16, device=self.device) for _ in range(2))

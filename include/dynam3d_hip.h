@@ -241,6 +241,16 @@ int32_t d3d_gemm_reserve_workspace(void* stream);
  * the epilogue.  x (n_rows, n_in) f16; weights: HOST array of n_hidden + 1 device pointers, layer l row-major (out_l, in_l)
  * with the last layer's rows zero-padded to n_out_padded (% 128; e.g. 769 -> 896); act / out_act: 0 none, 1 LeakyReLU(0.01);
  * scratch_a/b (n_rows, n_neurons) f16 each; y (n_rows, n_out_padded) f16. */
+/* The fused small-MLP kernel behind d3d_mlp768_forward and the tcnn.Network autograd function (csrc/mlp_kernels.hip): a chain of up to
+ * 4 bias-free layers y_l = f_l(y_{l-1} W_l^T) evaluated in ONE launch, a 64-row slab of activations resident in LDS across the layers,
+ * weights streamed from L2.  widths[0..n_layers]: input width then every layer's (padded) output width (% 16, <= 896; contraction widths
+ * % 32); weights[l]: (widths[l+1], widths[l]) row-major; modes[l]: 0 none, 1 LeakyReLU(0.01), 2 = multiply by LeakyReLU'(aux[l]) -- the
+ * data-gradient chain of the backward pass (weights = the transposed matrices, aux[l] = the saved forward activation below);
+ * outs[l]: optional HBM copy of layer l's output (saved activations / per-layer gradients), required for the last layer.  All arrays
+ * are HOST arrays of n_layers entries read during the call.  dtype 0 bf16 / 1 fp16.  Rounding points = the unfused d3d_gemm_nt path. */
+int32_t d3d_mlp_fused(const void* x_d, int64_t ldx, int64_t n_rows, int32_t n_layers, const int32_t* widths, const void* const* weights,
+                      const int32_t* modes, const void* const* aux, const int64_t* ld_aux, void* const* outs, const int64_t* ld_outs,
+                      int32_t dtype, void* stream);
 int32_t d3d_mlp768_forward(const void* x_d, int64_t n_rows, int32_t n_in, const void* const* weights, int32_t n_hidden,
                            int32_t n_neurons, int32_t n_out_padded, int32_t act, int32_t out_act, void* scratch_a_d,
                            void* scratch_b_d, void* y_d, void* stream);

@@ -106,3 +106,29 @@ def test_tcnn_backward_keeps_tiny_gradients_and_odd_input_widths():
         errs = dict(dx=rel(xg.grad.float().cpu(), xr.grad), **{f"dW{l}": rel(g, w.grad) for l, (g, w) in enumerate(zip(gl, wr))})
         print("tcnn backward", n_in, dy_scale, {k: f"{v:.2e}" for k, v in errs.items()})
         assert all(v < tol for v in errs.values()), errs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("out_act,n_out,rows", [("LeakyReLU", 769, 1152), ("None", 768, 9216), ("None", 768, 77)])
+def test_tcnn_fused_kernel_equals_per_layer_gemms_bit_for_bit(out_act, n_out, rows, monkeypatch):
+    """d3d_mlp_fused (ONE launch per network: the 64-row activation slab stays in LDS across the layers; forward AND the data-gradient
+    chain of the backward pass) against the unfused path (one d3d_gemm_nt launch per layer): same K order, same rounding points ->
+    identical bits in y, dx and every dW."""
+    from dynam3d_amd import tcnn
+    torch.manual_seed(9)
+    net = tcnn.Network(768, n_out, CFG(out_act), device="cuda", seed=21)
+    x = (torch.randn(rows, 768) * 0.8).cuda()
+    dy = (torch.randn(rows, n_out) * 0.05).cuda()
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(tcnn, "FUSED", fused)
+        net.params.grad = None
+        xg = x.clone().requires_grad_(True)
+        y = net(xg)
+        y.backward(dy)
+        with torch.no_grad():
+            y_inf = net(x)
+        res[fused] = (y.detach().clone(), xg.grad.clone(), net.params.grad.clone(), y_inf.clone())
+    for a, b, what in zip(res[True], res[False], ("y", "dx", "dparams", "y (inference call)")):
+        assert torch.equal(a, b), (what, float((a.float() - b.float()).abs().max()))
+    assert torch.equal(res[True][0], res[True][3])
