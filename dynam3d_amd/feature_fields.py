@@ -308,11 +308,14 @@ class Feature_Fields:
     def update_feature_fields(self, batch_depth, batch_grid_ft, batch_image=None, batch_position=None, batch_heading=None,
                               batch_camera_intrinsic=None, batch_rot=None, batch_trans=None, depth_scale=1000.0,
                               depth_trunc=1000.0, num_of_views=1, patch_segm=None, view_ids=None, batch_image_ft=None,
-                              is_training=False):
+                              is_training=False, trainer=None):
         """`num_of_views` (VLN-FF:493: view ix at heading - ix*pi/6) or `view_ids` (PRE-FF:843,920: view ix at
         heading - view_ids[ix]*pi/6, e.g. [0,3,6,9] = the four 90-degree views of `Net_3DFF.forward`, PRE-POL:160)."""
-        if is_training:
-            raise NotImplementedError("pre-training losses: SURVEY.md 8f-1")
+        if is_training and trainer is None:
+            raise ValueError("is_training=True needs trainer=train_ff.FFTrainer(...): it collects the loss terms (PRE-FF:969-1047, 1302-1345) "
+                             "and hands ground-truth merge decisions back to the memory update (dynam3d_amd/train_ff.py)")
+        if not is_training:
+            trainer = None
         pinhole = batch_camera_intrinsic is not None
         a = self.args
         if pinhole:
@@ -381,7 +384,14 @@ class Feature_Fields:
             centroid, cell, geom7 = ops.group_stats7(pools, self._i32(tok_slot), self._i32(tok_row), self._i32(grp_off), G, self.cell_len)
             tok_fts = ops.gather_fts(pools, self._i32(tok_slot), self._i32(tok_row))
             valid_g = np.nonzero(counts.reshape(-1) > 0)[0]
-            new_fts_valid = self.dense.encode_patch_sets(tok_fts, geom7, counts.reshape(-1)[valid_g])
+            if trainer is not None:                                           # differentiable encoding + loss terms of this view (PRE-FF:940-1008)
+                img_ix = img_mean = None
+                if batch_image_ft is not None:
+                    bif = torch.stack([torch.as_tensor(np.asarray(_host(f)) if not isinstance(f, torch.Tensor) else f).to(self.device) for f in batch_image_ft]).float()
+                    img_ix, img_mean = bif[:, ix], bif.mean(1)
+                new_fts_valid = trainer.instances(self, ops, pools, envs, slots_h, rb, order, tok_fts, geom7, counts, valid_g, centroid, n_max, img_ix, img_mean)
+            else:
+                new_fts_valid = self.dense.encode_patch_sets(tok_fts, geom7, counts.reshape(-1)[valid_g])
             new_fts = torch.zeros((G, FTS), dtype=torch.float32, device=self.device)
             new_fts.index_copy_(0, torch.from_numpy(valid_g).to(self.device), new_fts_valid)
 
@@ -400,8 +410,11 @@ class Feature_Fields:
                 pe, ps_, pj = (torch.from_numpy(np.concatenate(x)).to(self.device) for x in (pair_e, pair_s, pair_j))
                 pair_inst = idx[pe, ps_, pj].contiguous()
                 pair_new = (pe * n_max + ps_).to(torch.int32).contiguous()
-                x = ops.merge_input(pools, new_fts, centroid, slot[pe].contiguous(), pair_inst, pair_new)
-                logits_full[pe, ps_, pj] = self.dense.merge_logits(x)
+                if trainer is not None:                                       # discriminator loss; the memory merges by ground truth (PRE-FF:1029-1047)
+                    logits_full[pe, ps_, pj] = trainer.merge(pools, slot[pe].contiguous(), pe, ps_, pj, pair_inst, len(envs))
+                else:
+                    x = ops.merge_input(pools, new_fts, centroid, slot[pe].contiguous(), pair_inst, pair_new)
+                    logits_full[pe, ps_, pj] = self.dense.merge_logits(x)
             d2_h, idx_h, logits_h, cell_h = d2.cpu().numpy(), idx.cpu().numpy(), logits_full.cpu().numpy(), cell.cpu().numpy()  # sync #2
 
             # ---- bookkeeping: new ids / merges ---------------------------------------------------------
@@ -423,6 +436,8 @@ class Feature_Fields:
                     m_lens.append(len(rows)); m_slot.append(self.slots[e]); m_inst.append(int(inst)); m_env.append(j_)
             self.last_debug.append(dbg)
             self._grow_slots("inst", max(st.count(e, st.SLOTS) for e in envs))
+            if trainer is not None:
+                trainer.new_instances(pools, new_s, new_r, new_src)
             if new_r:                                                        # VLN-FF:643-648
                 s, r, src = self._i32(new_s), self._i32(new_r), self._i32(new_src)
                 ops.scatter_rows(pools.inst_pos, s, r, centroid, src)

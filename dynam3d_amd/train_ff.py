@@ -1,0 +1,346 @@
+"""Pre-training step of the 3D feature field: the `is_training=True` branch of the Pretrain class's
+`update_feature_fields` (Dynam3D_Pretrain/src_3dff/models/feature_fields.py "PRE-FF":843-1345) and the trainer's optimisation step
+(Dynam3D_Pretrain/src_3dff/ss_trainer_3DFF.py "PRE-TR":479-526), on the same device-resident memory as inference.
+
+What trains: the patch->instance set encoder + its position embedding, the instance->zone set encoder + its position embedding and the
+merge discriminator (PRE-FF:134-161).  Per view and environment the reference
+  * encodes every 2D segment (PRE-FF:940-966) and aligns it with the mean CLIP feature of its patches, plainly and in the frame's
+    mean-centred subspace (PRE-FF:969-974),
+  * labels every segment with a ground-truth instance id: k = 1 nearest GT point per patch (`gt_pcd_tree.query`, PRE-FF:977-983; here
+    `d3d_knn` over the 1e5-1e6 GT points), majority vote,
+  * encodes the frame's instances as one zone and aligns it with the image-level CLIP feature (PRE-FF:989-1008),
+  * scores every (segment, proposal) pair with the merge discriminator and trains it with a class-balanced cross-entropy against
+    "same GT id" (PRE-FF:1029-1047); the memory update then MERGES BY GROUND TRUTH, not by the discriminator's argmax (PRE-FF:1035),
+  * sums contrastive / 5 + cosine terms into `sim_loss` (PRE-FF:1302-1330).
+`TrainableFF` evaluates exactly those expressions differentiably: every Linear runs forward AND backward on the float32 MFMA GEMM
+(`d3d_gemm_nt_f32`: y = x W^T, dx = dy W, dW = dy^T x), LayerNorm / GELU / the small set attention are PyTorch autograd expressions.
+`FFTrainer` plugs into `Feature_Fields.update_feature_fields(is_training=True, trainer=...)` at the two points where the reference's
+loss terms are born and hands detached features / ground-truth merge decisions back to the (unchanged) memory state machine.
+`pretrain_step` = PRE-TR:479-526: zero_grad, forward, NaN vote across ranks, backward, per-parameter NaN scrub, clip_grad_value_(10),
+bucketed gradient all-reduce (dist.all_reduce_gradients replaces DDP), optimizer step, weights re-synced into the inference path.
+Dropout (0.1 inside nn.TransformerEncoderLayer while the reference trains) is not applied: the step is deterministic."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from . import dist as DD
+from . import losses as LS
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def gemm_nt_f32(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """a (M, K) @ w (N, K)^T -> (M, N) float32 on d3d_gemm_nt_f32 (K zero-padded to 16, N to 4: transient copies, nothing cached --
+    the operands of a training step change every step)."""
+    from . import f32_ops  # noqa: F401  (registers the signature)
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    if M == 0 or N == 0:
+        return torch.zeros((M, N), dtype=torch.float32, device=a.device)
+    Kp, Np = (K + 15) // 16 * 16, (N + 3) // 4 * 4
+    if Kp != K or a.stride(1) != 1 or a.stride(0) % 4:
+        ap = torch.zeros((M, Kp), dtype=torch.float32, device=a.device)
+        ap[:, :K] = a
+        a = ap
+    if Kp != K or Np != N or not w.is_contiguous():
+        wp = torch.zeros((Np, Kp), dtype=torch.float32, device=w.device)
+        wp[:N, :K] = w
+        w = wp
+    y = torch.empty((M, Np), dtype=torch.float32, device=a.device)
+    _lib.check(lib.d3d_gemm_nt_f32(_p(a), _p(w), _p(y), None, None, M, Np, Kp, a.stride(0), Kp, Np, 0, _stream()))
+    return y[:, :N]
+
+
+class _LinearF32(torch.autograd.Function):
+    """y = x W^T + b with all three GEMMs (forward, dx, dW) on the float32 MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        y = gemm_nt_f32(x, w)
+        return y + b if b is not None else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = gemm_nt_f32(dy, w.t().contiguous()) if ctx.needs_input_grad[0] else None        # dy (M,N) @ W (N,K)
+        dw = gemm_nt_f32(dy.t().contiguous(), x.t().contiguous()) if ctx.needs_input_grad[1] else None   # dy^T (N,M) @ x (M,K)
+        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def lin(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    if not x.is_cuda:
+        return F.linear(x, w, b)
+    return _LinearF32.apply(x.reshape(-1, x.shape[-1]), w, b).view(*x.shape[:-1], w.shape[0])
+
+
+class TrainableFF(torch.nn.Module):
+    """The trainable parameters of `Feature_Fields` under the reference's state-dict keys, with differentiable evaluations."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda", n_head: int = 12):
+        super().__init__()
+        self.names = [k for k in state_dict if not k.startswith(("FastSAM", "nerf_", "patch_to_nerf_", "aggregate_patch_to_nerf_"))]
+        self.plist = torch.nn.ParameterList([torch.nn.Parameter(state_dict[k].detach().to(device, torch.float32).clone()) for k in self.names])
+        self.n_head = n_head
+
+    @property
+    def w(self) -> Dict[str, torch.Tensor]:
+        return dict(zip(self.names, self.plist))
+
+    def named_state(self) -> Dict[str, torch.Tensor]:
+        return {k: p.detach() for k, p in zip(self.names, self.plist)}
+
+    def mlp(self, x, name):                                     # nn.Sequential(Linear, LayerNorm, GELU, Linear)
+        w = self.w
+        h = lin(x, w[name + ".0.weight"], w[name + ".0.bias"])
+        h = F.layer_norm(h, (h.shape[-1],), w[name + ".1.weight"], w[name + ".1.bias"], 1e-5)
+        return lin(F.gelu(h), w[name + ".3.weight"], w[name + ".3.bias"])
+
+    def encoder(self, x, key_mask, name):
+        """x (G, L, D), key_mask (G, L) True = real token -> (G, D): post-LN TransformerEncoder x 2 + LayerNorm(1e-12), row 0 (PRE-FF:134-155)."""
+        w, H = self.w, self.n_head
+        G, L, D = x.shape
+        am = key_mask[:, None, None, :]
+        for i in range(2):
+            p = f"{name}.layers.{i}"
+            qkv = lin(x, w[p + ".self_attn.in_proj_weight"], w[p + ".self_attn.in_proj_bias"])
+            q, k, v = qkv.view(G, L, 3, H, D // H).permute(2, 0, 3, 1, 4)
+            a = F.scaled_dot_product_attention(q, k, v, attn_mask=am).transpose(1, 2).reshape(G, L, D)
+            a = lin(a, w[p + ".self_attn.out_proj.weight"], w[p + ".self_attn.out_proj.bias"])
+            x = F.layer_norm(x + a, (D,), w[p + ".norm1.weight"], w[p + ".norm1.bias"], 1e-5)
+            h = lin(F.gelu(lin(x, w[p + ".linear1.weight"], w[p + ".linear1.bias"])), w[p + ".linear2.weight"], w[p + ".linear2.bias"])
+            x = F.layer_norm(x + h, (D,), w[p + ".norm2.weight"], w[p + ".norm2.bias"], 1e-5)
+        return F.layer_norm(x[:, 0], (D,), w[name + ".norm.weight"], w[name + ".norm.bias"], 1e-12)
+
+    def encode_sets(self, emb, lens, which):
+        """emb (T, D) member tokens of G sets back to back -> (G, D) = encoder([CLS; members])[0]; sets padded per length bucket."""
+        enc, cls = f"aggregate_{which}_encoder", self.w[f"aggregate_{which}_embedding"]
+        lens = np.asarray(lens, np.int64)
+        G, D = len(lens), emb.shape[-1]
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        T = int(offs[-1])
+        src = torch.cat([emb, cls, torch.zeros_like(cls)], 0)          # row T = CLS, row T + 1 = padding
+        bucket = np.ceil(np.log2(np.maximum(lens, 1) + 1)).astype(np.int64)
+        outs, order = [], []
+        for bk in np.unique(bucket):
+            gs = np.nonzero(bucket == bk)[0]
+            L = int(lens[gs].max()) + 1
+            idx = np.full((len(gs), L), T + 1, np.int64)
+            idx[:, 0] = T
+            msk = np.zeros((len(gs), L), bool)
+            msk[:, 0] = True
+            for r, g in enumerate(gs):
+                n = int(lens[g])
+                idx[r, 1:1 + n] = np.arange(offs[g], offs[g] + n)
+                msk[r, 1:1 + n] = True
+            x = src.index_select(0, torch.from_numpy(idx).to(emb.device).view(-1)).view(len(gs), L, D)
+            outs.append(self.encoder(x, torch.from_numpy(msk).to(emb.device), enc))
+            order.append(gs)
+        inv = np.argsort(np.concatenate(order))
+        return torch.cat(outs, 0).index_select(0, torch.from_numpy(inv).to(emb.device))
+
+    def encode_patch_sets(self, tok_fts, geom7, lens):
+        return self.encode_sets(tok_fts + self.mlp(geom7, "patch_to_instance_position_embedding"), lens, "patch_to_instance")
+
+    def encode_zone_sets(self, inst_fts, geom4, lens):
+        return self.encode_sets(inst_fts + self.mlp(geom4, "instance_to_zone_position_embedding"), lens, "instance_to_zone")
+
+    def merge_logits(self, x):
+        return self.mlp(x, "instance_merge_discriminator")
+
+
+class FFTrainer:
+    """Collects the loss terms of one `update_feature_fields(is_training=True)` call (all views, all environments)."""
+
+    def __init__(self, model: TrainableFF, gt_xyz: Optional[Sequence[np.ndarray]] = None, gt_label: Optional[Sequence[np.ndarray]] = None):
+        self.model = model
+        self.set_gt(gt_xyz, gt_label)
+        self.gt_ids_of_slot: Dict[int, torch.Tensor] = {}          # memory slot -> (m_cap,) GT instance id of every instance row (PRE-FF global_gt_instance_ids)
+        self.begin()
+
+    def set_gt(self, gt_xyz, gt_label):
+        """Ground-truth point clouds per environment: xyz (Ng, 3) float32 world coordinates, labels (Ng,) int (PRE-FF gt_pcd_tree / gt_pcd_label)."""
+        self.gt_xyz, self.gt_label = gt_xyz, gt_label
+        self._gt_dev = None
+
+    def begin(self):
+        self.pred_i, self.tgt_i, self.pred_is, self.tgt_is = [], [], [], []
+        self.pred_z, self.tgt_z, self.pred_zs, self.tgt_zs = [], [], [], []
+        self.segm_terms: List[torch.Tensor] = []
+        self.debug: List[dict] = []
+
+    # ---- hook 1: the 2D instances of one view of every environment -------------------------------------------------------------------------
+    # (`Feature_Fields.update_feature_fields` runs under torch.no_grad(): the hooks re-enable autograd for the loss terms)
+    @torch.enable_grad()
+    def instances(self, ff, ops, pools, envs, slots_h, row_base, order, tok_fts, geom7, counts, valid_g, centroid, n_max, image_ft_ix, image_ft_mean):
+        """tok_fts (B*P, 768) patch features ordered (env, segment label, patch), geom7 (B*P, 7), counts (B, n_max) patches per segment,
+        valid_g: flat indices of the non-empty groups, centroid (B*n_max, 3).  image_ft_ix (B, 768) / image_ft_mean (B, 768): CLIP image
+        feature of this view / mean over the views (or None).  Returns the detached (len(valid_g), 768) instance features."""
+        m, dev = self.model, tok_fts.device
+        B, P = len(envs), ff.P
+        lens = counts.reshape(-1)[valid_g]
+        tok = tok_fts.float()
+        pred = m.encode_patch_sets(tok, geom7, lens)                                                   # PRE-FF:960-964
+        grp_of_tok = torch.from_numpy(np.repeat(np.arange(len(valid_g)), lens)).to(dev)
+        seg_mean = torch.zeros((len(valid_g), tok.shape[1]), device=dev).index_add_(0, grp_of_tok, tok) / torch.from_numpy(lens).to(dev).float()[:, None]
+        frame_mean = tok.view(B, P, -1).mean(1)                                                        # patch_fts.mean(0) of every environment
+        env_of_grp = torch.from_numpy(valid_g // n_max).to(dev)
+        fm = frame_mean.index_select(0, env_of_grp)
+        self.pred_i.append(pred); self.tgt_i.append(seg_mean)                                          # PRE-FF:969-974
+        self.pred_is.append(pred - fm); self.tgt_is.append(seg_mean - fm)
+        cen = centroid.index_select(0, torch.from_numpy(valid_g).to(dev))
+        if image_ft_ix is not None:                                                                    # PRE-FF:992-1008: the frame's instances as ONE zone
+            n_inst = np.bincount(valid_g // n_max, minlength=B)
+            cmean = torch.zeros((B, 3), device=dev).index_add_(0, env_of_grp, cen) / torch.from_numpy(np.maximum(n_inst, 1)).to(dev).float()[:, None]
+            geom4 = torch.cat([cen - cmean.index_select(0, env_of_grp), torch.sqrt((cen * cen).sum(-1, keepdim=True))], -1)
+            zone = m.encode_zone_sets(pred, geom4, n_inst)
+            self.pred_z.append(zone); self.tgt_z.append(image_ft_ix.float())
+            self.pred_zs.append(zone - image_ft_mean.float()); self.tgt_zs.append(image_ft_ix.float() - image_ft_mean.float())
+        # ground-truth instance id of every segment: nearest GT point of each patch (k = 1), majority vote (PRE-FF:977-983)
+        self.cur = dict(pred=pred, cen=cen, valid_g=valid_g, n_max=n_max, gt=None, inv=None)
+        inv = np.full(B * n_max, -1, np.int64)
+        inv[valid_g] = np.arange(len(valid_g))
+        self.cur["inv"] = torch.from_numpy(inv).to(dev)
+        if self.gt_xyz is not None:
+            self.cur["gt"] = torch.from_numpy(self._label_segments(ops, pools, envs, slots_h, row_base, order, counts, valid_g, n_max)).to(dev)
+        self.debug.append(dict(tok_fts=tok.detach(), geom7=geom7.detach(), lens=lens.copy(), cen=cen.detach(), env_of_group=(valid_g // n_max).copy(), B=B, P=P,
+                               img_ix=None if image_ft_ix is None else image_ft_ix.detach().float(), img_mean=None if image_ft_mean is None else image_ft_mean.detach().float(),
+                               gt=None if self.cur["gt"] is None else self.cur["gt"].clone(), pairs=None))
+        return pred.detach()
+
+    def _gt_device(self, dev):
+        if self._gt_dev is None:
+            cap = max(len(x) for x in self.gt_xyz)
+            pts = torch.zeros((len(self.gt_xyz), cap, 3), dtype=torch.float32, device=dev)
+            for e, x in enumerate(self.gt_xyz):
+                pts[e, :len(x)] = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+            self._gt_dev = (pts, cap, torch.tensor([len(x) for x in self.gt_xyz], dtype=torch.int32, device=dev))
+        return self._gt_dev
+
+    def _label_segments(self, ops, pools, envs, slots_h, row_base, order, counts, valid_g, n_max):
+        dev = pools.rows_pos.device
+        B, P = order.shape
+        pts, cap, n_pts = self._gt_device(dev)
+        rows = torch.from_numpy((np.asarray(row_base, np.int64)[:, None] + order).astype(np.int64)).to(dev)       # (B, P) rows in (label, patch) order
+        q = torch.stack([pools.rows_pos[int(slots_h[j])].index_select(0, rows[j]) for j in range(B)]).contiguous()   # (B, P, 3) world positions
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+        sel = pts if len(envs) == pts.shape[0] else pts.index_select(0, torch.tensor(list(envs), device=dev))
+        npts = n_pts if len(envs) == pts.shape[0] else n_pts.index_select(0, torch.tensor(list(envs), device=dev))
+        _d2, idx = ops.knn(sel.contiguous(), cap * 3, npts.contiguous(), q, P * 3, i32([P] * B), i32([1] * B), B, P, 1)
+        idx_h = idx.view(B, P).cpu().numpy()
+        out = np.zeros(len(valid_g), np.int64)
+        off = np.concatenate([np.zeros((B, 1), np.int64), np.cumsum(counts, 1)], 1)
+        for gi, g in enumerate(valid_g):
+            j, s = divmod(int(g), n_max)
+            lab = np.asarray(self.gt_label[envs[j]])[idx_h[j, off[j, s]:off[j, s + 1]]]
+            vals, cnt = np.unique(lab, return_counts=True)
+            out[gi] = vals[cnt.argmax()]                                                               # unique_vals[counts.argmax()]
+        return out
+
+    # ---- hook 2: merge proposals ------------------------------------------------------------------------------------------------------------
+    @torch.enable_grad()
+    def merge(self, pools, slot_of_pair, pe, ps_, pj, pair_inst, n_envs):
+        """(environment pe, segment ps_, proposal pj) pairs with instance row pair_inst.  Returns (pairs, 2) logits that make the memory merge
+        by GROUND TRUTH when GT ids exist (PRE-FF:1031-1035), else by the discriminator's argmax (PRE-FF:1063)."""
+        m, c = self.model, self.cur
+        dev = c["pred"].device
+        g = c["inv"].index_select(0, (pe * c["n_max"] + ps_).long())
+        f3 = pools.inst_fts[slot_of_pair.long(), pair_inst.long()]
+        p3 = pools.inst_pos[slot_of_pair.long(), pair_inst.long()]
+        x = torch.cat([f3, c["pred"].index_select(0, g), c["cen"].index_select(0, g) - p3], -1)       # [ft_3d, ft_2d, position offset] (PRE-FF:1023-1026)
+        logits = m.merge_logits(x)
+        if c["gt"] is None:
+            return logits.detach()
+        gt3 = torch.stack([self._slot_gt(int(s), pools)[int(i)] for s, i in zip(slot_of_pair.tolist(), pair_inst.tolist())]).to(dev)
+        target = (gt3 == c["gt"].index_select(0, g)).long()
+        for j in range(n_envs):                                                                        # one cross-entropy per (environment, view)
+            sel = pe == j
+            if bool(sel.any()):
+                t = LS.segmentation_loss(logits[sel], target[sel])
+                if t is not None:
+                    self.segm_terms.append(t)
+        self.debug[-1]["pairs"] = dict(f3=f3.detach(), p3=p3.detach(), g=g.clone(), target=target.clone(), pe=pe.clone())
+        return torch.stack([1.0 - target.float(), target.float()], -1)                                 # argmax = the ground-truth decision
+
+    def _slot_gt(self, slot, pools):
+        cap = pools.inst_pos.shape[1]
+        t = self.gt_ids_of_slot.get(slot)
+        if t is None or t.shape[0] < cap:
+            n = torch.full((cap,), -1, dtype=torch.int64)
+            if t is not None:
+                n[: t.shape[0]] = t
+            self.gt_ids_of_slot[slot] = t = n
+        return t
+
+    def new_instances(self, pools, new_slots, new_rows, new_src):
+        """Instance rows created by this view: remember their GT id (PRE-FF:1091-1097)."""
+        if self.cur["gt"] is None:
+            return
+        gt = self.cur["gt"].cpu()
+        inv = self.cur["inv"].cpu()
+        for s, r, src in zip(new_slots, new_rows, new_src):
+            self._slot_gt(int(s), pools)[int(r)] = gt[int(inv[int(src)])]
+
+    # ---- PRE-FF:1302-1345 ---------------------------------------------------------------------------------------------------------------------
+    @torch.enable_grad()
+    def losses(self):
+        cat = lambda xs: torch.cat(xs, 0)
+        zone = bool(self.pred_z)
+        sim = LS.alignment_loss(cat(self.pred_i), cat(self.tgt_i), cat(self.pred_is), cat(self.tgt_is),
+                                cat(self.pred_z) if zone else None, cat(self.tgt_z) if zone else None,
+                                cat(self.pred_zs) if zone else None, cat(self.tgt_zs) if zone else None)
+        # every trainable module takes part in every step (PRE-FF:1340 "Avoid DDP bug"): keeps the ranks' gradient sets identical
+        dummy = self.model.merge_logits(torch.zeros((1, 2 * 768 + 3), device=sim.device)).sum() * 0.0
+        segm = torch.stack(self.segm_terms).mean() if self.segm_terms else None
+        return sim + dummy, segm
+
+
+def pretrain_step(ff, trainer: FFTrainer, optimizer, update_kwargs: dict, clip_value: float = 10.0) -> dict:
+    """One optimisation step (PRE-TR:479-526) on `ff` (a `Feature_Fields(variant="pretrain")`): forward with loss collection, NaN vote over
+    the ranks, backward, NaN scrub, value clipping, gradient all-reduce, optimizer step; the updated weights are copied into the
+    inference-path modules of `ff`.  Returns {'loss', 'sim_loss', 'segm_loss', 'skipped', 'collectives'}."""
+    optimizer.zero_grad(set_to_none=True)
+    trainer.begin()
+    ff.update_feature_fields(is_training=True, trainer=trainer, **update_kwargs)
+    sim, segm = trainer.losses()
+    loss = sim if segm is None else sim + segm
+    out = dict(loss=float(loss.detach()), sim_loss=float(sim.detach()), segm_loss=None if segm is None else float(segm.detach()), skipped=False, collectives=0)
+    if DD.any_nan_vote(loss.detach()):                                 # PRE-TR:503-509: a NaN on any rank skips the step on every rank
+        out["skipped"] = True
+        return out
+    loss.backward()
+    params = list(trainer.model.parameters())
+    for p in params:                                                   # PRE-TR:513-515
+        if p.grad is not None:
+            torch.nan_to_num_(p.grad, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
+    torch.nn.utils.clip_grad_value_(params, clip_value)                # PRE-TR:517
+    zero = lambda p: torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()
+    trainer.local_grads = {k: zero(p) for k, p in zip(trainer.model.names, trainer.model.plist)}      # (kept for the tests)
+    out["collectives"] = DD.all_reduce_gradients(params, nan_to_zero=False)
+    trainer.last_grads = {k: zero(p) for k, p in zip(trainer.model.names, trainer.model.plist)}
+    optimizer.step()
+    sync_weights(ff, trainer.model)
+    return out
+
+
+def sync_weights(ff, model: TrainableFF):
+    """The no-grad memory path (`FFDense`: merged-instance re-encoding, zone update, inference) reads its own float32 copies."""
+    for k, v in model.named_state().items():
+        if k in ff.dense.w:
+            ff.dense.w[k].copy_(v)
