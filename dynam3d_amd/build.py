@@ -29,6 +29,7 @@ HIP_SOURCES = [
     ("decode_kernels.hip", ["-ffp-contract=fast"]),
     ("render_kernels.hip", ["-ffp-contract=off"]),
     ("mlp_kernels.hip", ["-ffp-contract=fast"]),
+    ("segment_kernels.hip", ["-ffp-contract=off"]),
 ]
 CPP_SOURCES = ["ff_state.cpp", "d3d_error.cpp", "phi3_decode.cpp", "mlp_forward.cpp"]
 HOST_CPP_SOURCES = ["ff_state.cpp", "d3d_error.cpp"]      # the CPU-only bookkeeping library (no device entry points)

@@ -7,9 +7,15 @@ patch grid, dense relabel in `torch.unique` order; a failing / empty segmentatio
 reference's `except` branch (VLN-FF:424-426)."""
 from __future__ import annotations
 
+import ctypes as _C
 from typing import Callable, Optional, Sequence
 
 import torch
+
+from . import _lib
+
+_lib.register("d3d_segment_slic", [_C.c_void_p, _C.c_int32, _C.c_int32, _C.c_int32, _C.c_int32, _C.c_int32, _C.c_int32, _C.c_float, _C.c_void_p,
+                                   _C.c_void_p, _C.c_void_p])
 
 
 class MaskSegmenter:
@@ -42,4 +48,38 @@ class MaskSegmenter:
             off.append(off[-1] + (0 if m is None else m.shape[0]))
         masks = torch.cat([m for m in per_image if m is not None]).contiguous()
         segm, _ = self.ops.patch_segm_from_masks(masks, off, h, w)
+        return segm
+
+
+class SlicSegmenter:
+    """segmenter(batch_image) -> (N,1,24,24) int64 dense labels with the masks GENERATED ON THE DEVICE: `d3d_segment_slic`
+    (grid-seeded colour + position k-means, csrc/segment_kernels.hip) produces gx * gy disjoint masks per frame in one launch for the whole
+    batch, `d3d_patch_segm_from_masks` turns them into the label map exactly as it does for FastSAM's masks (VLN-FF:411-420).  A stand-in for
+    the reference's FastSAM network (whose weights are not available offline), behind the same callable: pass it as
+    `Feature_Fields(segmenter=SlicSegmenter(ops))` / `Dynam3D_VLN(segmenter=...)` and the step needs no `patch_segm` input."""
+
+    def __init__(self, ops, seeds=(4, 4), iters: int = 5, compactness: float = 20.0, grid_hw=(24, 24), device="cuda"):
+        self.ops, self.seeds, self.iters, self.compactness, self.grid_hw, self.device = ops, seeds, iters, compactness, grid_hw, torch.device(device)
+        self._C = _C
+
+    def masks(self, batch_image, return_labels: bool = False):
+        """batch_image: (N,H,W,3) uint8 tensor / array (or a sequence of (H,W,3) images of one size) -> masks (N, K, H, W) uint8 on the device."""
+        C = self._C
+        if isinstance(batch_image, (list, tuple)):
+            batch_image = torch.stack([torch.as_tensor(i) for i in batch_image])
+        img = torch.as_tensor(batch_image).to(self.device, torch.uint8).contiguous()
+        if img.dim() == 5:                                              # (B, V, H, W, 3) -> frames, environment-major like the reference's batch_image
+            img = img.reshape(-1, *img.shape[2:])
+        N, H, W, _ = img.shape
+        gy, gx = self.seeds
+        masks = torch.empty((N, gx * gy, H, W), dtype=torch.uint8, device=self.device)
+        labels = torch.empty((N, H, W), dtype=torch.int32, device=self.device) if return_labels else None
+        _lib.check(self.ops.lib.d3d_segment_slic(C.c_void_p(img.data_ptr()), N, H, W, gx, gy, self.iters, float(self.compactness), C.c_void_p(masks.data_ptr()),
+                                                 None if labels is None else C.c_void_p(labels.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return (masks, labels) if return_labels else masks
+
+    def __call__(self, batch_image, **kw) -> torch.Tensor:
+        masks = self.masks(batch_image)
+        N, K = masks.shape[:2]
+        segm, _ = self.ops.patch_segm_from_masks(masks.view(N * K, *masks.shape[2:]), [i * K for i in range(N + 1)], *self.grid_hw)
         return segm

@@ -70,6 +70,14 @@ int32_t d3d_resize_nearest_preprocess(const float* depth_d, float* out_d, int32_
 int32_t d3d_patch_segm_from_masks(const uint8_t* masks_d, const int32_t* mask_off_d, int32_t n_img, int32_t max_masks,
                                   int32_t H, int32_t W, int32_t h, int32_t w, int32_t* segm_d, int32_t* n_seg_d, void* stream);
 
+/* f-3  An on-device class-agnostic mask generator for get_patch_segm (VLN-FF:400-430) while FastSAM's weights are unavailable: grid-seeded
+ * colour + position k-means (SLIC-style) over all pixels, one workgroup per image, deterministic (integer cluster sums; restated bit for
+ * bit by oracle/segment_ref.py).  rgb_d (n_img,H,W,3) u8; gx * gy <= 64 seeds; `iters` Lloyd updates + the final assignment;
+ * compactness m: distance = |d rgb|^2 + (m / S)^2 |d xy|^2 with S the seed spacing.  masks_d (n_img, gx*gy, H, W) u8 {0,1} -- the input of
+ * d3d_patch_segm_from_masks (clusters without pixels give all-zero masks, which the relabel drops); labels_d (n_img,H,W) i32 or NULL. */
+int32_t d3d_segment_slic(const uint8_t* rgb_d, int32_t n_img, int32_t H, int32_t W, int32_t gx, int32_t gy, int32_t iters, float compactness,
+                         uint8_t* masks_d, int32_t* labels_d, void* stream);
+
 /* camera tables for a5/a13 are uploaded once per camera setting by the host wrapper:
  * tan_xy[P], tan_z[P], dir0[P] (see oracle/geometry.py::camera_tables; VLN-FF:283-287). */
 
