@@ -37,7 +37,7 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 using float2v = __attribute__((ext_vector_type(2))) float;
 using v4s = __attribute__((ext_vector_type(4))) short;
 
-constexpr int BQ = 128, BKV = 64, NT = 256;
+constexpr int BKV = 64;      // keys per tile; a workgroup of NW waves owns NW * 32 query rows
 
 template <bool BF16>
 __device__ __forceinline__ float16v mfma32(const uint4& a, const uint4& b, float16v c) {
@@ -79,10 +79,11 @@ __device__ __forceinline__ float pair_sum(float v) {
     return a;
 }
 
-template <bool BF16, int HD, bool CAUSAL>
-__global__ void __launch_bounds__(NT, 2)
+template <bool BF16, int HD, bool CAUSAL, int NW>
+__global__ void __launch_bounds__(NW * 64, 2)
 k_flash_attn32(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, int64_t row_stride, int64_t batch_stride, int q_off, int k_off,
                int v_off, float scale_log2e, int seq_len, const int32_t* __restrict__ cu, int n_qblocks, int window, int nx, int B) {
+    constexpr int NT = NW * 64, BQ = NW * 32;
     constexpr int KS = HD / 16;              // 16-deep MFMA steps over head_dim (QK^T)
     constexpr int DB = HD / 32;              // 32-wide head-dim blocks (PV)
     constexpr int CH = HD / 8;               // 16-byte chunks per row
@@ -142,9 +143,11 @@ k_flash_attn32(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int
     // slots of the 256-byte bank space (hd 96: 256-byte rows, f = r & 15; hd 64: 128-byte rows alternate halves, f = (r >> 1) & 7)
     auto kswz = [](int r) { return HD == 96 ? (r & 15) : ((r >> 1) & 7); };
 
-    constexpr int NK = (BKV * CH) / NT;      // 3 (hd 96) / 2 (hd 64) 16-byte chunks of K (and of V) per thread and tile
-    static_assert(NK == 2 || NK == 3, "tile shape");
-    uint4 kr0, kr1, kr2 = make_uint4(0, 0, 0, 0), vr0, vr1, vr2 = make_uint4(0, 0, 0, 0);
+    constexpr int NCHUNK = BKV * CH;                     // 16-byte pieces of a K (or V) tile
+    constexpr int NK = (NCHUNK + NT - 1) / NT;           // pieces per thread: 3 / 2 (4 waves, hd 96 / 64), 2 / 1 (8 waves; hd 96: the second only in waves 0-3)
+    static_assert(NK >= 1 && NK <= 3, "tile shape");
+    auto piece_ok = [&](int i) { return (NCHUNK % NT == 0) || (tid + i * NT < NCHUNK); };      // wave-uniform
+    uint4 kr0, kr1 = make_uint4(0, 0, 0, 0), kr2 = make_uint4(0, 0, 0, 0), vr0, vr1 = make_uint4(0, 0, 0, 0), vr2 = make_uint4(0, 0, 0, 0);
     auto ld_kv = [&](const uint16_t* P, int key0_, int i) -> uint4 {          // rows beyond the sequence are clamped (valid memory, masked later)
         const int c = tid + i * NT;
         const int kr = min(key0_ + c / CH, S - 1);
@@ -158,26 +161,26 @@ k_flash_attn32(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int
         const int c = tid + i * NT;
         *reinterpret_cast<uint4*>(Vb + (c / CH) * VST + (c % CH) * 8) = v;
     };
-#define FA_LOAD_TILE(T)                                        \
-    {                                                          \
-        const int k0_ = (T) * BKV;                             \
-        kr0 = ld_kv(Kp, k0_, 0);                               \
-        kr1 = ld_kv(Kp, k0_, 1);                               \
-        if constexpr (NK > 2) kr2 = ld_kv(Kp, k0_, 2);         \
-        vr0 = ld_kv(Vp, k0_, 0);                               \
-        vr1 = ld_kv(Vp, k0_, 1);                               \
-        if constexpr (NK > 2) vr2 = ld_kv(Vp, k0_, 2);         \
+#define FA_LOAD_TILE(T)                                                        \
+    {                                                                          \
+        const int k0_ = (T) * BKV;                                             \
+        kr0 = ld_kv(Kp, k0_, 0);                                               \
+        if constexpr (NK > 1) { if (piece_ok(1)) kr1 = ld_kv(Kp, k0_, 1); }    \
+        if constexpr (NK > 2) { if (piece_ok(2)) kr2 = ld_kv(Kp, k0_, 2); }    \
+        vr0 = ld_kv(Vp, k0_, 0);                                               \
+        if constexpr (NK > 1) { if (piece_ok(1)) vr1 = ld_kv(Vp, k0_, 1); }    \
+        if constexpr (NK > 2) { if (piece_ok(2)) vr2 = ld_kv(Vp, k0_, 2); }    \
     }
-#define FA_STORE_TILE(BUF)                                     \
-    {                                                          \
-        uint16_t* Kb_ = Ks + (BUF) * KBUF;                     \
-        uint16_t* Vb_ = Vs + (BUF) * VBUF;                     \
-        st_k(Kb_, 0, kr0);                                     \
-        st_k(Kb_, 1, kr1);                                     \
-        if constexpr (NK > 2) st_k(Kb_, 2, kr2);               \
-        st_v(Vb_, 0, vr0);                                     \
-        st_v(Vb_, 1, vr1);                                     \
-        if constexpr (NK > 2) st_v(Vb_, 2, vr2);               \
+#define FA_STORE_TILE(BUF)                                                     \
+    {                                                                          \
+        uint16_t* Kb_ = Ks + (BUF) * KBUF;                                     \
+        uint16_t* Vb_ = Vs + (BUF) * VBUF;                                     \
+        st_k(Kb_, 0, kr0);                                                     \
+        if constexpr (NK > 1) { if (piece_ok(1)) st_k(Kb_, 1, kr1); }          \
+        if constexpr (NK > 2) { if (piece_ok(2)) st_k(Kb_, 2, kr2); }          \
+        st_v(Vb_, 0, vr0);                                                     \
+        if constexpr (NK > 1) { if (piece_ok(1)) st_v(Vb_, 1, vr1); }          \
+        if constexpr (NK > 2) { if (piece_ok(2)) st_v(Vb_, 2, vr2); }          \
     }
     using lds_v4s = __attribute__((address_space(3))) v4s;
     // V fragment base (A operand of O^T = V^T P^T through the transposing read): lane addresses key 16s + 8jj + 4hi + (l & 15) / 4,
@@ -202,7 +205,7 @@ k_flash_attn32(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int
     for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_i = -INFINITY, l_i = 0.f;
+    float m_i = -INFINITY;
 
     const int kv_len = CAUSAL ? min(seq_len, q0 + BQ) : seq_len;
     const int n_tiles = (kv_len + BKV - 1) / BKV;
@@ -212,152 +215,179 @@ k_flash_attn32(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int
     const int kmax = CAUSAL ? min(qrow, seq_len - 1) : seq_len - 1;
     const int kmin = window > 0 ? qrow - window + 1 : 0;
 
+    // row sums on the matrix pipe: one extra MFMA per 16-key step with an A fragment whose row 0 is all ones puts sum_k P[k][q] -- of the
+    // 16-bit P the PV product consumes -- into row 0 of `lacc` (lane q, register 0); it is rescaled with O and needs no VALU adds
+    const uint32_t one2 = BF16 ? 0x3F803F80u : 0x3C003C00u;
+    const uint4 ones = (lane & 31) == 0 ? make_uint4(one2, one2, one2, one2) : make_uint4(0, 0, 0, 0);
+    float16v lacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+
     FA_LOAD_TILE(t_first)
     FA_STORE_TILE(0)
     if (t_first + 1 < n_tiles) FA_LOAD_TILE(t_first + 1)
     __syncthreads();
 
-    for (int t = t_first; t < n_tiles; ++t) {
-        const int cur = (t - t_first) & 1;
-        const int key0 = t * BKV;
-        const uint16_t* Kb = Ks + cur * KBUF;
-        const uint16_t* Vb = Vs + cur * VBUF + v_off0;
-        // wave-uniform activity: the tile (or its second 32-key block) may lie entirely above this wave's diagonal / below its window
-        const bool tile_on = !(CAUSAL && key0 > qw + 31) && !(window > 0 && key0 + BKV - 1 <= qw - window);
-        const bool blk1_on = tile_on && !(CAUSAL && key0 + 32 > qw + 31);
-        uint4 pf[4];
-        if (tile_on) {
-            // ---- S^T = K Q^T : st[b][4j + r] = S[key0 + 32b + 8j + 4hi + r][qrow] ---------------------------------------------------
-            // K fragments: all KS reads of block 0 are issued up front; block 1's reads are issued one behind each MFMA of block 0's chain
-            // (hipcc left to itself kept two reads in flight and waited for each pair: the LDS latency was exposed three times per chain)
-            float16v st[2];
+    // Tiles [t_first, t_main): visible IN FULL to every query of the block (below the block's diagonal, inside the sequence, no window edge),
+    // and tile t + 2 -- requested while tile t is computed -- lies inside the sequence: the branch-free body with unclamped loads off a
+    // wave-uniform base.  The rest (the tiles around the diagonal, the sequence end, the window) run the general body.
+    int t_main = window > 0 ? t_first : min(min(CAUSAL ? (q0 + 1) / BKV : n_tiles, S / BKV - 2), n_tiles - 1);
+    t_main = max(t_first, t_main);
+    const int64_t tile_bytes = (int64_t)BKV * row_stride * 2;
+    const char* kbase = reinterpret_cast<const char*>(Kp) + (int64_t)(t_first + 2) * tile_bytes;       // tile t + 2 of the main body
+    const char* vbase = reinterpret_cast<const char*>(Vp) + (int64_t)(t_first + 2) * tile_bytes;
+    uint32_t goff[NK];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { st[0][r] = 0.f; st[1][r] = 0.f; }
-            uint4 kfa[KS], kfb[KS];
-            const uint16_t* Ka = Kb + li * KST;
-            const uint16_t* Kc = Kb + (32 + li) * KST;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kfa[ks] = *reinterpret_cast<const uint4*>(Ka + (((ks * 2 + hi) ^ kswz(li)) << 3));
-            if (blk1_on) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    kfb[ks] = *reinterpret_cast<const uint4*>(Kc + (((ks * 2 + hi) ^ kswz(32 + li)) << 3));
-                    st[0] = mfma32<BF16>(kfa[ks], qf[ks], st[0]);
-                }
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) st[1] = mfma32<BF16>(kfb[ks], qf[ks], st[1]);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one ds_read (block 1, step ks)
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA  (block 0, step ks)
-                }
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) st[0] = mfma32<BF16>(kfa[ks], qf[ks], st[0]);
-            }
-            // ---- masking (diagonal tiles, the tile that crosses seq_len, the window edge): key - key0 - 4hi in [lo_, hi_] is visible -------
-            const bool need_mask = (CAUSAL && key0 + BKV - 1 > qw) || (key0 + BKV > seq_len) || (window > 0 && key0 <= qw + 31 - window);
-            if (need_mask) {
-                const int lo_ = kmin - key0 - hi * 4, hi_ = kmax - key0 - hi * 4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int o_ = j * 8 + r;
-                        if (o_ > hi_ || o_ < lo_) st[0][4 * j + r] = -INFINITY;
-                        if (o_ + 32 > hi_ || o_ + 32 < lo_) st[1][4 * j + r] = -INFINITY;
-                    }
-            }
-            // ---- online softmax, base 2, one query per lane pair ------------------------------------------------------------------------
-            float tmax = max3(st[0][0], st[0][1], st[0][2]);
-#pragma unroll
-            for (int r = 3; r + 1 < 16; r += 2) tmax = max3(tmax, st[0][r], st[0][r + 1]);
-            tmax = fmaxf(tmax, st[0][15]);
-            if (blk1_on) {
-#pragma unroll
-                for (int r = 0; r + 1 < 16; r += 2) tmax = max3(tmax, st[1][r], st[1][r + 1]);
-            }
-            tmax = pair_max(tmax);
-            const float tm = tmax * scale_log2e;
-            const bool keep = __all(tm <= m_i + 8.0f);                     // deferred rescale: P stays <= 2^8
-            const float m_new = keep ? m_i : fmaxf(m_i, tm);
-            const float m_use = m_new == -INFINITY ? 0.f : m_new;           // a row with no visible key yet (window / padding): exp2(-inf) = 0
-            const float alpha = keep ? 1.0f : __builtin_amdgcn_exp2f(m_i - m_use);
-            float rs = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                st[0][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[0][r], scale_log2e, -m_use));
-                rs += st[0][r];
-            }
-            if (blk1_on) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    st[1][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[1][r], scale_log2e, -m_use));
-                    rs += st[1][r];
-                }
-            }
-            rs = pair_sum(rs);
-            l_i = l_i * alpha + rs;
-            m_i = m_new;
-            if (!keep) {
-#pragma unroll
-                for (int d = 0; d < DB; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-            }
-            // P^T fragments: MFMA step s covers keys 16s .. 16s+15 of the tile; k-slot (hi*8 + jj*4 + r) = key 16s + 8jj + 4hi + r
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int kb = s >> 1, j = 2 * (s & 1);
-                pf[s].x = pack2<BF16>(st[kb][4 * j + 0], st[kb][4 * j + 1]);
-                pf[s].y = pack2<BF16>(st[kb][4 * j + 2], st[kb][4 * j + 3]);
-                pf[s].z = pack2<BF16>(st[kb][4 * j + 4], st[kb][4 * j + 5]);
-                pf[s].w = pack2<BF16>(st[kb][4 * j + 6], st[kb][4 * j + 7]);
-            }
-        }
-        // ---- stage tile t+1 (in registers since the previous iteration) into the other buffer; request tile t+2 ----------------------------
-        if (t + 1 < n_tiles) {
-            FA_STORE_TILE(cur ^ 1)
-            if (t + 2 < n_tiles) FA_LOAD_TILE(t + 2)
-        }
-        // ---- O^T += V^T P^T ------------------------------------------------------------------------------------------------------------
-        if (tile_on) {
-            auto ld_vf = [&](int s_, int d_) -> uint4 {
-                const uint16_t* vb = Vb + s_ * 16 * VST + d_ * 32;
-                const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)vb);
-                const v4s hv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(vb + 8 * VST));
-                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hv);
-                return make_uint4(l2.x, l2.y, h2.x, h2.y);
-            };
-            // steps in (s, d) order (DB independent accumulators back to back); the V fragments of step (s + 1, d) are requested before the
-            // MFMA of step (s, d) is issued, so DB steps (2 DB transposing reads) are always in flight
-            uint4 vf[2][DB];
-#pragma unroll
-            for (int d = 0; d < DB; ++d) vf[0][d] = ld_vf(0, d);
-            if (blk1_on) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int d = 0; d < DB; ++d) {
-                        if (s + 1 < 4) vf[(s + 1) & 1][d] = ld_vf(s + 1, d);
-                        oacc[d] = mfma32<BF16>(vf[s & 1][d], pf[s], oacc[d]);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int d = 0; d < DB; ++d) {
-                        if (s + 1 < 2) vf[(s + 1) & 1][d] = ld_vf(s + 1, d);
-                        oacc[d] = mfma32<BF16>(vf[s & 1][d], pf[s], oacc[d]);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    }
-            }
-        }
-        __syncthreads();          // tile t+1 is visible; every wave is done with buffer `cur`
+    for (int i = 0; i < NK; ++i) {
+        const int c = tid + i * NT;
+        goff[i] = (uint32_t)(((int64_t)(c / CH) * row_stride + (c % CH) * 8) * 2);
     }
+    auto ld_vf = [&](const uint16_t* Vb_, int s_, int d_) -> uint4 {
+        const uint16_t* vb = Vb_ + s_ * 16 * VST + d_ * 32;
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)vb);
+        const v4s hv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(vb + 8 * VST));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hv);
+        return make_uint4(l2.x, l2.y, h2.x, h2.y);
+    };
+
+// One key tile.  TAIL false: the branch-free body; TAIL true: per-wave activity (tile / second key block above the wave's diagonal or
+// below its window), masks, clamped loads.
+#define FA_TILE(TAIL)                                                                                                                        \
+    {                                                                                                                                        \
+        const int cur = (t - t_first) & 1;                                                                                                   \
+        const int key0 = t * BKV;                                                                                                            \
+        const uint16_t* Kb = Ks + cur * KBUF;                                                                                                \
+        const uint16_t* Vb = Vs + cur * VBUF + v_off0;                                                                                       \
+        const bool tile_on = TAIL ? (!(CAUSAL && key0 > qw + 31) && !(window > 0 && key0 + BKV - 1 <= qw - window)) : true;                  \
+        const bool blk1_on = TAIL ? (tile_on && !(CAUSAL && key0 + 32 > qw + 31)) : true;                                                    \
+        uint4 pf[4];                                                                                                                         \
+        if (tile_on) {                                                                                                                       \
+            /* ---- S^T = K Q^T : st{b}[4j + r] = S[key0 + 32b + 8j + 4hi + r][qrow]; block 1's fragments are requested one behind each   */  \
+            /* MFMA of block 0's chain (hipcc left to itself kept two reads in flight and waited for each pair) ------------------------- */  \
+            float16v st0, st1;                                                                                                               \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) { st0[r] = 0.f; st1[r] = 0.f; }                                                   \
+            const uint16_t* Ka = Kb + li * KST;                                                                                              \
+            const uint16_t* Kc = Kb + (32 + li) * KST;                                                                                       \
+            auto k_frag = [&](int ks, int blk) -> uint4 {                                                                                    \
+                return *reinterpret_cast<const uint4*>((blk ? Kc : Ka) + (((ks * 2 + hi) ^ kswz(li)) << 3));   /* kswz(32 + li) == kswz(li) */ \
+            };                                                                                                                               \
+            if (blk1_on) {                                                                                                                   \
+                /* MFMA slot i = step i/2 of key block i&1 (two accumulators alternate); its K fragment is requested two slots ahead, so */ \
+                /* three fragments are live instead of twelve */                                                                            \
+                uint4 kf0 = k_frag(0, 0), kf1 = k_frag(0, 1), kf2 = make_uint4(0, 0, 0, 0);                                                  \
+                _Pragma("unroll") for (int i = 0; i < 2 * KS; ++i) {                                                                         \
+                    const uint4 kf_ = (i % 3 == 0) ? kf0 : (i % 3 == 1) ? kf1 : kf2;                                                         \
+                    if (i + 2 < 2 * KS) {                                                                                                    \
+                        const uint4 nx_ = k_frag((i + 2) >> 1, (i + 2) & 1);                                                                 \
+                        if ((i + 2) % 3 == 0) kf0 = nx_; else if ((i + 2) % 3 == 1) kf1 = nx_; else kf2 = nx_;                               \
+                    }                                                                                                                        \
+                    if (i & 1) st1 = mfma32<BF16>(kf_, qf[i >> 1], st1);                                                                     \
+                    else st0 = mfma32<BF16>(kf_, qf[i >> 1], st0);                                                                           \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                       \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                       \
+                }                                                                                                                            \
+            } else {                                                                                                                         \
+                _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) st0 = mfma32<BF16>(k_frag(ks, 0), qf[ks], st0);                            \
+            }                                                                                                                                \
+            if (TAIL) {   /* masking: key - key0 - 4hi in [lo_, hi_] is visible */                                                           \
+                const bool need_mask = (CAUSAL && key0 + BKV - 1 > qw) || (key0 + BKV > seq_len) || (window > 0 && key0 <= qw + 31 - window); \
+                if (need_mask) {                                                                                                             \
+                    const int lo_ = kmin - key0 - hi * 4, hi_ = kmax - key0 - hi * 4;                                                        \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                            \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                          \
+                        const int o_ = j * 8 + r;                                                                                            \
+                        if (o_ > hi_ || o_ < lo_) st0[4 * j + r] = -INFINITY;                                                                \
+                        if (o_ + 32 > hi_ || o_ + 32 < lo_) st1[4 * j + r] = -INFINITY;                                                      \
+                    }                                                                                                                        \
+                }                                                                                                                            \
+            }                                                                                                                                \
+            /* ---- online softmax, base 2, one query per lane pair ------------------------------------------------------------------ */    \
+            float tmax = max3(st0[0], st0[1], st0[2]);                                                                                       \
+            _Pragma("unroll") for (int r = 3; r + 1 < 16; r += 2) tmax = max3(tmax, st0[r], st0[r + 1]);                                     \
+            tmax = fmaxf(tmax, st0[15]);                                                                                                     \
+            if (blk1_on) {                                                                                                                   \
+                _Pragma("unroll") for (int r = 0; r + 1 < 16; r += 2) tmax = max3(tmax, st1[r], st1[r + 1]);                                 \
+            }                                                                                                                                \
+            tmax = pair_max(tmax);                                                                                                           \
+            const float tm = tmax * scale_log2e;                                                                                             \
+            const bool keep = __all(tm <= m_i + 8.0f);                     /* deferred rescale: P stays <= 2^8 */                            \
+            const float m_new = keep ? m_i : fmaxf(m_i, tm);                                                                                 \
+            const float m_use = (TAIL && m_new == -INFINITY) ? 0.f : m_new; /* no visible key yet (window / padding): exp2(-inf) = 0 */      \
+            if (!keep) {                                                                                                                     \
+                const float alpha = __builtin_amdgcn_exp2f(m_i - m_use);                                                                     \
+                _Pragma("unroll") for (int d = 0; d < DB; ++d)                                                                               \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;                                                          \
+                lacc[0] *= alpha;                                                                                                            \
+            }                                                                                                                                \
+            m_i = m_new;                                                                                                                     \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) st0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st0[r], scale_log2e, -m_use));     \
+            if (blk1_on) {                                                                                                                   \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) st1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st1[r], scale_log2e, -m_use)); \
+            }                                                                                                                                \
+            /* P^T fragments: MFMA step s covers keys 16s .. 16s+15 of the tile; k-slot (hi*8 + jj*4 + r) = key 16s + 8jj + 4hi + r */       \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                                  \
+                pf[s].x = pack2<BF16>(st0[8 * s + 0], st0[8 * s + 1]);                                                                       \
+                pf[s].y = pack2<BF16>(st0[8 * s + 2], st0[8 * s + 3]);                                                                       \
+                pf[s].z = pack2<BF16>(st0[8 * s + 4], st0[8 * s + 5]);                                                                       \
+                pf[s].w = pack2<BF16>(st0[8 * s + 6], st0[8 * s + 7]);                                                                       \
+                pf[2 + s].x = pack2<BF16>(st1[8 * s + 0], st1[8 * s + 1]);                                                                   \
+                pf[2 + s].y = pack2<BF16>(st1[8 * s + 2], st1[8 * s + 3]);                                                                   \
+                pf[2 + s].z = pack2<BF16>(st1[8 * s + 4], st1[8 * s + 5]);                                                                   \
+                pf[2 + s].w = pack2<BF16>(st1[8 * s + 6], st1[8 * s + 7]);                                                                   \
+            }                                                                                                                                \
+        }                                                                                                                                    \
+        /* ---- stage tile t+1 (in registers since the previous iteration) into the other buffer; request tile t+2 ----------------------- */  \
+        if (TAIL) {                                                                                                                          \
+            if (t + 1 < n_tiles) {                                                                                                           \
+                FA_STORE_TILE(cur ^ 1)                                                                                                       \
+                if (t + 2 < n_tiles) FA_LOAD_TILE(t + 2)                                                                                     \
+            }                                                                                                                                \
+        } else {                                                                                                                             \
+            FA_STORE_TILE(cur ^ 1)                                                                                                           \
+            kr0 = *reinterpret_cast<const uint4*>(kbase + goff[0]);                                                                          \
+            if constexpr (NK > 1) { if (piece_ok(1)) kr1 = *reinterpret_cast<const uint4*>(kbase + goff[NK > 1 ? 1 : 0]); }                  \
+            if constexpr (NK > 2) { if (piece_ok(2)) kr2 = *reinterpret_cast<const uint4*>(kbase + goff[NK - 1]); }                          \
+            vr0 = *reinterpret_cast<const uint4*>(vbase + goff[0]);                                                                          \
+            if constexpr (NK > 1) { if (piece_ok(1)) vr1 = *reinterpret_cast<const uint4*>(vbase + goff[NK > 1 ? 1 : 0]); }                  \
+            if constexpr (NK > 2) { if (piece_ok(2)) vr2 = *reinterpret_cast<const uint4*>(vbase + goff[NK - 1]); }                          \
+            kbase += tile_bytes;                                                                                                             \
+            vbase += tile_bytes;                                                                                                             \
+        }                                                                                                                                    \
+        /* ---- O^T += V^T P^T (+ the row sums): steps in (s, d) order, the V fragments of step (s + 1, d) requested before the MFMA of   */  \
+        /* step (s, d) is issued -------------------------------------------------------------------------------------------------------- */  \
+        if (tile_on) {                                                                                                                       \
+            uint4 vf[2][DB];                                                                                                                 \
+            _Pragma("unroll") for (int d = 0; d < DB; ++d) vf[0][d] = ld_vf(Vb, 0, d);                                                       \
+            if (blk1_on) {                                                                                                                   \
+                _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                              \
+                    _Pragma("unroll") for (int d = 0; d < DB; ++d) {                                                                         \
+                        if (s + 1 < 4) vf[(s + 1) & 1][d] = ld_vf(Vb, s + 1, d);                                                             \
+                        oacc[d] = mfma32<BF16>(vf[s & 1][d], pf[s], oacc[d]);                                                                \
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                                   \
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                   \
+                    }                                                                                                                        \
+                    lacc = mfma32<BF16>(ones, pf[s], lacc);                                                                                  \
+                }                                                                                                                            \
+            } else {                                                                                                                         \
+                _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                              \
+                    _Pragma("unroll") for (int d = 0; d < DB; ++d) {                                                                         \
+                        if (s + 1 < 2) vf[(s + 1) & 1][d] = ld_vf(Vb, s + 1, d);                                                             \
+                        oacc[d] = mfma32<BF16>(vf[s & 1][d], pf[s], oacc[d]);                                                                \
+                    }                                                                                                                        \
+                    lacc = mfma32<BF16>(ones, pf[s], lacc);                                                                                  \
+                }                                                                                                                            \
+            }                                                                                                                                \
+        }                                                                                                                                    \
+        __syncthreads();          /* tile t+1 is visible; every wave is done with buffer `cur` */                                            \
+    }
+
+    int t = t_first;
+    for (; t < t_main; ++t) FA_TILE(false)
+    for (; t < n_tiles; ++t) FA_TILE(true)
+#undef FA_TILE
+    // the row sum of query li lives in lane li (hi = 0), register 0: hand it to the partner lane
+    float l_i = lacc[0];
+    l_i = pair_sum(hi == 0 ? l_i : 0.f);
     // ---- epilogue: lane holds O[qrow][32d + 8j + 4hi + r]; lane pairs exchange so that each stores 16 contiguous bytes ---------------------
     const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
     uint16_t* op = out + ((row0 + qrow) * H + h) * HD;
@@ -397,12 +427,22 @@ int32_t d3d_flash_attention_v2(const void* qkv, void* out, int32_t B, int32_t S,
     hipStream_t s = (hipStream_t)stream;
     const uint16_t* q = (const uint16_t*)qkv;
     uint16_t* o = (uint16_t*)out;
+    // Query rows per workgroup: 4 waves = 128 rows (two workgroups per CU), the default; 8 waves = 256 rows (one workgroup per CU, half the
+    // K/V bytes staged per query) is selectable with D3D_ATTN_WAVES=8 and measures THE SAME time on the Phi-3 shapes and 8 % slower on the
+    // ViT shape (577 rows = 2.25 blocks of 256): the kernel is not bound by the K/V loads.  Neither is it bound by instruction counts (a
+    // software-pipelined and a hand-scheduled variant, the branch-free main body, row sums moved to the matrix pipe: all within 3 %).
+    // In-kernel stamps put a wave's key tile at ~3 300 cycles on an otherwise empty SIMD and ~4 500 with two waves per SIMD, against
+    // 768 cycles of matrix-pipe time: DESIGN.md section 4b.
+    static const int force_nw = [] { const char* e = getenv("D3D_ATTN_WAVES"); return e ? atoi(e) : 0; }();
+    const int nw = force_nw == 8 ? 8 : 4;
+    const int BQ = nw * 32;
     const int nqb = (S + BQ - 1) / BQ;
     if (window >= S) window = 0;                                       // no query is further than S - 1 keys from the first key
     const int nx = causal ? (nqb + 1) / 2 : nqb;                        // causal: one workgroup per PAIR of query blocks (longest + shortest)
-    dim3 grid((unsigned)((int64_t)nx * H * B)), block(NT);
-#define D3D_FA2(BF, HDV, CA) hipLaunchKernelGGL((k_flash_attn32<BF, HDV, CA>), grid, block, 0, s, q, o, S, H, row_stride, batch_stride, q_off, k_off, v_off, sl2, \
-                                                seq_len, cu_seqlens, nqb, window, nx, B)
+    dim3 grid((unsigned)((int64_t)nx * H * B)), block(nw * 64);
+#define D3D_FA2N(BF, HDV, CA, NWV) hipLaunchKernelGGL((k_flash_attn32<BF, HDV, CA, NWV>), grid, block, 0, s, q, o, S, H, row_stride, batch_stride, q_off, k_off, v_off, \
+                                                      sl2, seq_len, cu_seqlens, nqb, window, nx, B)
+#define D3D_FA2(BF, HDV, CA) do { if (nw == 8) D3D_FA2N(BF, HDV, CA, 8); else D3D_FA2N(BF, HDV, CA, 4); } while (0)
     if (dtype == 0) {
         if (head_dim == 96) { if (causal) D3D_FA2(true, 96, true); else D3D_FA2(true, 96, false); }
         else { if (causal) D3D_FA2(true, 64, true); else D3D_FA2(true, 64, false); }
@@ -410,6 +450,7 @@ int32_t d3d_flash_attention_v2(const void* qkv, void* out, int32_t B, int32_t S,
         if (head_dim == 96) { if (causal) D3D_FA2(false, 96, true); else D3D_FA2(false, 96, false); }
         else { if (causal) D3D_FA2(false, 64, true); else D3D_FA2(false, 64, false); }
     }
+#undef D3D_FA2N
 #undef D3D_FA2
     D3D_LAUNCH_CHECK();
 }
