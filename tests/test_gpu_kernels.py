@@ -127,6 +127,26 @@ def test_knn_large_batched_vs_oracle(ops):
         assert np.array_equal(bits(d2[b, :nq[b], :kk].cpu().numpy()), bits(ed))
 
 
+def test_knn_renderer_query_count_bit_exact(ops):
+    """The renderer's regime by COUNT (2 x 136 000 queries in one call): ragged query / point counts, ties, tomb-stones, k < k_max.
+    (A four-queries-per-thread variant with packed float32 arithmetic was built against this test, bit-exact, and measured SLOWER than
+    one query per thread -- 2.5 against 2.2 ms per 8-view render call: with a quarter of the waves the loop is latency-bound -- and dropped.)"""
+    rng = np.random.default_rng(12)
+    nb, P, Q, k = 2, 1500, 136000, 4
+    pts = rng.uniform(-6, 6, (nb, P, 3)).astype(np.float32)
+    pts[:, ::53] = -10000.0
+    pts[:, 7] = pts[:, 907]
+    q = rng.uniform(-6, 6, (nb, Q, 3)).astype(np.float32)
+    q[:, 0] = pts[:, 7]
+    q[:, 1::4099] = pts[:, None, 7]                                  # exact hits on the duplicated point scattered over the four per-thread slots
+    npts, nq = np.array([P, P - 333], np.int32), np.array([Q, Q - 1029], np.int32)
+    d2, idx = ops.knn(dev(pts), P * 3, dev(npts), dev(q), Q * 3, dev(nq), dev(np.array([k, 2], np.int32)), nb, Q, 4)
+    for b, kk in enumerate((4, 2)):
+        ed, ei = G.knn_bruteforce(pts[b, :npts[b]], q[b, :nq[b]], kk)
+        assert np.array_equal(idx[b, :nq[b], :kk].cpu().numpy().astype(np.int64), ei)
+        assert np.array_equal(bits(d2[b, :nq[b], :kk].cpu().numpy()), bits(ed))
+
+
 def test_depth_preprocess_and_resize_bit_exact(ops):
     rng = np.random.default_rng(3)
     for H, W in ((224, 224), (256, 256), (37, 53)):
