@@ -61,9 +61,10 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 }
 
 __device__ __forceinline__ float max3(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
+    // NOT inline asm: the hazard recogniser does not see an asm statement as a VALU read, so the wait states a VALU needs after the MFMA
+    // that wrote its operands were not inserted and a max taken straight off the score accumulators read registers still in flight
+    // (run-to-run differences in the last bits).  hipcc folds the nested maxima into v_max3_f32 by itself.
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
 }
 // op(v, value of lane ^ 32): v_permlane32_swap exchanges the upper half of vdst with the lower half of src; with both operands holding
 // the same value, op(vdst', src') is the xor-32 butterfly.  Inline asm: the builtin folds away when both operands are the same SSA

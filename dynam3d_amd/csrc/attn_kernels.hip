@@ -46,9 +46,10 @@ using v4s = __attribute__((ext_vector_type(4))) short;
 // needs before v_permlane*_swap reads it, LLVM gfx950 hazard rule.)
 using float2v = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ float max3(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
+    // NOT inline asm: the hazard recogniser does not see an asm statement as a VALU read, so the wait states a VALU needs after the MFMA
+    // that wrote its operands were not inserted and a max taken straight off the score accumulators read registers still in flight
+    // (run-to-run differences in the last bits).  hipcc folds the nested maxima into v_max3_f32 by itself.
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
 }
 __device__ __forceinline__ float row_max4(float v) {
     float a = v, b = v;
