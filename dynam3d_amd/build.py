@@ -23,6 +23,7 @@ HIP_SOURCES = [
     ("tower_kernels.hip", ["-ffp-contract=off"]),
     ("train_kernels.hip", ["-ffp-contract=off"]),
     ("f32_kernels.hip", ["-ffp-contract=off"]),
+    ("f32x3_kernels.hip", ["-ffp-contract=off"]),
     ("gemm_kernels.hip", ["-ffp-contract=fast"]),
     ("attn_kernels.hip", ["-ffp-contract=fast"]),
     ("attn2_kernels.hip", ["-ffp-contract=fast"]),

@@ -4,6 +4,7 @@ pick the kernel by shape; weights whose K is not a multiple of 16 are zero-padde
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -12,6 +13,7 @@ from . import _lib
 from ._lib import f32, i32, i64, vp
 
 _lib.register("d3d_gemm_nt_f32", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp])
+_lib.register("d3d_gemm_nt_f32x3", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp])
 _lib.register("d3d_linear_smallk_f32", [vp, vp, vp, vp, i32, i32, i32, i64, i64, i32, vp])
 _lib.register("d3d_linear_smalln_f32", [vp, vp, vp, vp, i32, i32, i32, i64, i64, vp])
 _lib.register("d3d_layer_norm_f32", [vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, f32, i32, vp])
@@ -28,14 +30,19 @@ def _stream():
 
 
 class F32Ops:
+    # The float32 GEMMs run as split-precision fp16 MFMAs (hi hi + hi lo + lo hi, float32 accumulation: csrc/f32x3_kernels.hip) --
+    # float32 accuracy at 16-bit matrix rate.  D3D_F32_SPLIT=0 (or F32Ops.SPLIT = False) selects the v_mfma_f32_16x16x4_f32 kernel.
+    SPLIT = os.environ.get("D3D_F32_SPLIT", "1") != "0"
+    KPAD = 32                                        # both kernels take K % 32 == 0 (the float32 one needs 16)
+
     def __init__(self):
         self.lib = _lib.load()
         self._padded: Dict[tuple, torch.Tensor] = {}
 
     def prep_weight(self, w: torch.Tensor) -> torch.Tensor:
-        """(N, K) float32 contiguous; K zero-padded to a multiple of 16 for the MFMA kernel (cached per tensor)."""
+        """(N, K) float32 contiguous; K zero-padded to a multiple of 32 for the MFMA kernels (cached per tensor)."""
         N, K = w.shape
-        if K % 16 == 0 or K <= 8 or N <= 8:
+        if K % self.KPAD == 0 or K <= 8 or N <= 8:
             return w
         # keyed on the storage AND its version counter: an in-place update (optimizer step, load_state_dict) or a new tensor allocated
         # at a freed address must not be served another tensor's / an older padded copy; one entry per address, so updates replace
@@ -43,7 +50,7 @@ class F32Ops:
         tag = (w._version, N, K)
         hit = self._padded.get(key)
         if hit is None or hit[0] != tag:
-            wp = torch.zeros((N, (K + 15) // 16 * 16), dtype=torch.float32, device=w.device)
+            wp = torch.zeros((N, (K + self.KPAD - 1) // self.KPAD * self.KPAD), dtype=torch.float32, device=w.device)
             wp[:, :K] = w.detach()
             hit = self._padded[key] = (tag, wp)
         return hit[1]
@@ -78,7 +85,8 @@ class F32Ops:
             epi = "bias_res"
         else:
             epi = "bias_gelu" if act == "gelu" else "bias"
-        _lib.check(self.lib.d3d_gemm_nt_f32(_p(x), _p(wp), _p(y), _p(b), _p(residual), M, N, Kp, x.stride(0), Kp, N, EPI[epi], _stream()))
+        gemm = self.lib.d3d_gemm_nt_f32x3 if self.SPLIT else self.lib.d3d_gemm_nt_f32
+        _lib.check(gemm(_p(x), _p(wp), _p(y), _p(b), _p(residual), M, N, Kp, x.stride(0), Kp, N, EPI[epi], _stream()))
         return y
 
     def layer_norm(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None, gelu: bool = False) -> torch.Tensor:

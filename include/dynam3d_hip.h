@@ -269,6 +269,11 @@ int32_t d3d_mlp768_forward(const void* x_d, int64_t n_rows, int32_t n_in, const 
  * K % 16 == 0 (zero-pad operands), N % 4 == 0, strides % 4 == 0. */
 int32_t d3d_gemm_nt_f32(const float* A_d, const float* W_d, float* C_d, const float* bias_d, const float* residual_d, int32_t M, int32_t N,
                         int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t epilogue, void* stream);
+/* Same contract, on the 16-bit matrix cores at float32 accuracy: each float32 element is split into fp16 hi + lo while its tile is
+ * staged and the product taken as three fp16 MFMAs (hi hi + hi lo + lo hi) with float32 accumulation -- ~1e-6 relative to a float32
+ * GEMM, 5.3x its matrix peak (csrc/f32x3_kernels.hip).  K % 32 == 0; |operand| < 65504.  The inference token builder's default. */
+int32_t d3d_gemm_nt_f32x3(const float* A_d, const float* W_d, float* C_d, const float* bias_d, const float* residual_d, int32_t M, int32_t N,
+                          int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t epilogue, void* stream);
 /* y = [gelu](x W^T + b) for 1 <= K <= 8 (geometry inputs of the position-embedding MLPs; W (N,K) contiguous) */
 int32_t d3d_linear_smallk_f32(const float* x_d, const float* W_d, const float* bias_d, float* y_d, int32_t M, int32_t N, int32_t K, int64_t ldx,
                               int64_t ldy, int32_t gelu, void* stream);

@@ -26,8 +26,15 @@ for M, N, K, act in ((4736, 2304, 768, None), (4736, 768, 768, None), (4736, 307
                      (9000, 2304, 768, None), (128, 2304, 768, None), (128, 3072, 768, "gelu"), (128, 768, 3072, None), (300, 3072, 1552, None), (600, 768, 768, None)):
     x, w, b = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * K ** -0.5, torch.randn(N, device="cuda")
     own = lambda: f.linear(x, w, b, act=act)
+    def own32():
+        f.SPLIT = False
+        try:
+            return f.linear(x, w, b, act=act)
+        finally:
+            f.SPLIT = True
+    f.SPLIT = True
     ref = (lambda: F.gelu(F.linear(x, w, b))) if act else (lambda: F.linear(x, w, b))
-    t_own, t_ref = timeit(own), timeit(ref)
+    t_own, t_ref, t_32 = timeit(own), timeit(ref), timeit(own32)
     fl = 2.0 * M * N * K / 1e9
     err = float((own().double() - ref().double()).norm() / ref().double().norm())
-    print(f"M={M:5d} N={N:5d} K={K:5d} {act or '':5s} own {t_own * 1e3:7.1f} us ({fl / t_own:6.1f} TF/s)   torch {t_ref * 1e3:7.1f} us ({fl / t_ref:6.1f} TF/s)   rel diff {err:.1e}")
+    print(f"M={M:5d} N={N:5d} K={K:5d} {act or '':5s} split {t_own * 1e3:7.1f} us ({fl / t_own:6.1f} TF/s)   f32-mfma {t_32 * 1e3:7.1f} us ({fl / t_32:6.1f} TF/s)   torch {t_ref * 1e3:7.1f} us ({fl / t_ref:6.1f} TF/s)   rel diff {err:.1e}")
