@@ -28,6 +28,7 @@ _lib.register("d3d_phi3_decode_token", [vp])
 _lib.register("d3d_phi3_decode_status", [vp])
 _lib.register("d3d_patchify", [vp, vp, i32, i32, i32, i32, i32, vp])
 _lib.register("d3d_vit_embed_ln", [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp])
+_lib.register("d3d_assemble_prompt", [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp])
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -188,6 +189,16 @@ class HipDense:
         out = torch.empty((B, L, D), dtype=patch_rows.dtype, device=patch_rows.device)
         _lib.check(self.lib.d3d_vit_embed_ln(_p(patch_rows), _p(cls), _p(pos), _p(ln_w), _p(ln_b), _p(out), B, L, D, eps,
                                              0 if patch_rows.dtype == torch.bfloat16 else 1, self._stream()))
+        return out
+
+    def assemble_prompt(self, desc, embed, patch_feat, patch_pos, inst, zone, rows):
+        """The packed prompt rows of all environments in one pass (d3d_assemble_prompt): desc (rows,) int32 = (source << 28) | row."""
+        D, dt = embed.shape[1], embed.dtype
+        for t in (patch_feat, patch_pos, inst, zone):
+            assert t.dtype == dt and t.is_contiguous() and t.shape[-1] == D, (t.dtype, t.shape)
+        out = torch.empty((rows, D), dtype=dt, device=embed.device)
+        _lib.check(self.lib.d3d_assemble_prompt(_p(desc), _p(embed), _p(patch_feat), _p(patch_pos), _p(inst), _p(zone), _p(out), rows, D,
+                                                0 if dt == torch.bfloat16 else 1, self._stream()))
         return out
 
     def resize_normalize(self, rgb_u8, size, mean, std):

@@ -274,6 +274,8 @@ class Dynam3D_VLN:
         prompt tokenised with one "<image>" per visual token (VLN-POL:436-438, 456): `PromptTokenizer.split_prompt`."""
         return self.tokenizer.split_prompt(self.PROMPT_HEAD, n_visual, self._prompt_text(b, instructions))
 
+    ASSEMBLE_KERNEL = True          # packed prompt rows by d3d_assemble_prompt (one pass); False: the PyTorch expressions below (the test's reference)
+
     def _assemble_packed(self, patch_feat, patch_pos, inst_tok, zone_tok, ni, nz, instructions, B, V):
         """Same rows as `_assemble_rows`, written once, in the LM's dtype, back to back (no per-environment tensors, no
         padding): one id upload + one embedding gather for all prompts, one add for all patch tokens, one row gather into
@@ -281,6 +283,28 @@ class Dynam3D_VLN:
         ff, dt = self.feature_fields, self.cfg.llava_dtype
         P = V * ff.P
         parts = [self._prompt_ids(b, instructions, P + ni[b] + nz[b]) for b in range(B)]        # (head ids, tail ids) per prompt
+        emb_w = self.llm.embed_w
+        if (self.ASSEMBLE_KERNEL and patch_feat.is_cuda and D.BACKEND["linear"] == "hip" and dt in (torch.bfloat16, torch.float16)
+                and all(t.dtype == dt for t in (emb_w, patch_feat, patch_pos, inst_tok, zone_tok))):
+            # one kernel writes every row from its source (csrc/tower_kernels.hip k_assemble_prompt): the host only builds the row table
+            desc, lengths = [], []
+            i_off, z_off = 0, 0
+            for b in range(B):                                                                 # VLN-POL:456 row order
+                h_ids, t_ids = parts[b]
+                desc.append(np.concatenate([np.asarray(h_ids, np.int64), (1 << 28) + b * P + np.arange(P), (2 << 28) + i_off + np.arange(ni[b]),
+                                            (3 << 28) + z_off + np.arange(nz[b]), np.asarray(t_ids, np.int64)]))
+                lengths.append(len(h_ids) + P + ni[b] + nz[b] + len(t_ids))
+                i_off, z_off = i_off + ni[b], z_off + nz[b]
+            T = int(sum(lengths))
+            Tp = (T + 255) // 256 * 256
+            table = np.full(Tp, 7 << 28, np.int64)                                             # zero rows behind the last prompt
+            table[:T] = np.concatenate(desc)
+            x = D._hip.assemble_prompt(torch.from_numpy(table.astype(np.uint32).view(np.int32)).to(self.device), emb_w,
+                                        patch_feat.reshape(B * P, -1).contiguous(), patch_pos.reshape(B * P, -1).contiguous(),
+                                        inst_tok.contiguous(), zone_tok.contiguous(), Tp)
+            self.last_lengths = lengths
+            self.last_counts = dict(Ni=ni, Nz=nz)
+            return x, lengths
         ids = torch.tensor([i for h, t in parts for i in h + t], device=self.device)
         emb = self.llm.embed_tokens(ids).to(dt)                                                # rows [0, E): head_0, tail_0, head_1, ...
         patch_tok = (patch_feat.reshape(B * P, -1).float() + patch_pos.reshape(B * P, -1).float()).to(dt)   # VLN-POL:448-453

@@ -388,6 +388,12 @@ int32_t d3d_patchify(const float* pixels_d, void* out_d, int32_t B, int32_t S, i
  * rounded to the 16-bit dtype before ln_pre, as the reference's 16-bit add is.  cls (D), pos (L,D), patch_rows (B*(L-1),D), y (B*L,D). */
 int32_t d3d_vit_embed_ln(const void* patch_rows_d, const void* cls_d, const void* pos_d, const float* ln_w_d, const float* ln_b_d, void* y_d,
                          int32_t B, int32_t L, int32_t D, float eps, int32_t dtype, void* stream);
+/* The packed Phi-3 prompt of all environments in one pass (VLN-POL:448-456).  Output row t (of `rows`, a multiple of 256; row stride D)
+ * is selected by desc_d[t] = (source << 28) | source_row: 0 embedding-table row, 1 patch token = patch_feat[row] + patch_pos[row] added in
+ * float32 and rounded once (VLN-POL:448-453), 2 instance token, 3 zone token, 7 zero row.  All tensors (.., D) contiguous in `dtype`
+ * (0 bf16 / 1 fp16), D % 8 == 0. */
+int32_t d3d_assemble_prompt(const uint32_t* desc_d, const void* embed_d, const void* patch_feat_d, const void* patch_pos_d, const void* inst_d,
+                            const void* zone_d, void* out_d, int32_t rows, int32_t D, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pretrain novel-view renderer.  The 768-wide tcnn MLPs (PRE-FF:221-243, 484, 488) are

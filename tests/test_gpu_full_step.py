@@ -83,6 +83,38 @@ def test_full_config_step_prune_determinism_packed_vs_single(full_net):
     assert not c["fallback"], c
 
 
+def test_packed_prompt_kernel_equals_torch_assembly(full_net):
+    """`d3d_assemble_prompt` (one pass over the row table) writes exactly the rows the PyTorch expressions of `_assemble_packed` build
+    (embedding gather, float32 patch add rounded once, cat, row gather -- VLN-POL:448-456), padding rows included, at the bench shapes."""
+    from dynam3d_amd.synthetic import INSTRUCTION_64, SyntheticEpisodes
+    net, B = full_net, 8
+    net.feature_fields.reset(B)
+    ep = SyntheticEpisodes(B, seed=4)
+    instr = [INSTRUCTION_64[: 40 + 7 * b] for b in range(B)]                     # ragged instruction lengths
+    for step in range(3):
+        obs, pos, hd, segm = _frame(ep)
+        net.feature_fields.history_actions = [["forward\n"] * (step + b % 2) + ["none\n"] * 2 for b in range(B)]       # ragged tails
+        calls = {}
+        orig = net._assemble_packed
+
+        def spy(*a, **k):
+            calls["args"] = a
+            return orig(*a, **k)
+        net._assemble_packed = spy
+        try:
+            x_k, lens_k = net.build_inputs(obs, instr, pos, hd, patch_segm=segm, return_rows="packed")
+        finally:
+            net._assemble_packed = orig
+        type(net).ASSEMBLE_KERNEL = False
+        try:
+            x_t, lens_t = orig(*calls["args"])
+        finally:
+            type(net).ASSEMBLE_KERNEL = True
+        assert lens_k == lens_t and x_k.shape == x_t.shape and x_k.dtype == x_t.dtype
+        assert torch.equal(x_k, x_t), float((x_k.float() - x_t.float()).abs().max())
+        assert float(x_k[sum(lens_k):].abs().max()) == 0.0
+
+
 def test_config3_rollout_8_episodes_50_steps_full_model(full_net):
     """BASELINE configs[3] on one rank: 8 concurrent episodes, max_traj_len 50 (VLN/scripts/iter_train.yaml:41), the full model."""
     from dynam3d_amd.rollout import run_rollout
