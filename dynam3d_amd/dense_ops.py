@@ -183,9 +183,10 @@ def rope_packed_(qkv2d: torch.Tensor, n_rot_heads: int, head_dim: int, cos, sin,
     return qkv2d
 
 
-def attention_packed(qkv3: torch.Tensor, n_heads: int, causal: bool, cu_seqlens: torch.Tensor, n_seq: int, max_len: int, n_valid=None, window: int = 0):
+def attention_packed(qkv3: torch.Tensor, n_heads: int, causal: bool, cu_seqlens: torch.Tensor, n_seq: int, max_len: int, n_valid=None, window: int = 0,
+                     out=None):
     _hit("attention")
-    return _hip.attention_packed(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid, window)
+    return _hip.attention_packed(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid, window, out)
 
 
 def decode_attention(qkv_new, prompt_qkv, cu_seqlens, knew, vnew, n_heads: int, t_new: int, max_prompt_len: int, rope=None):

@@ -246,11 +246,14 @@ class HipDense:
                                                 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
         return out
 
-    def attention_packed(self, qkv, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid=None, window=0):
+    def attention_packed(self, qkv, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid=None, window=0, out=None):
         """PACKED variable-length batch: qkv (T, 3H, hd) rows of sequence b = [cu[b], cu[b+1]) -> (T, H, hd).  Rows beyond
-        cu[-1] (padding of the packed buffer) come back zero; `n_valid` = cu[-1] as a host int saves zero-filling the rest."""
+        cu[-1] (padding of the packed buffer) come back zero; `n_valid` = cu[-1] as a host int saves zero-filling the rest.
+        `out`: a caller-owned (T, H, hd) buffer whose padding rows are already zero (the kernel writes rows < cu[-1] only)."""
         T, Ht, hd = qkv.shape
-        if n_valid is None:
+        if out is not None:
+            assert out.shape == (T, n_heads, hd) and out.dtype == qkv.dtype and out.is_contiguous()
+        elif n_valid is None:
             out = torch.zeros((T, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
         else:
             out = torch.empty((T, n_heads, hd), dtype=qkv.dtype, device=qkv.device)

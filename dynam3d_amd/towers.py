@@ -272,13 +272,16 @@ class Phi3Decoder:
         return self.embed_w.index_select(0, ids.reshape(-1)).view(*ids.shape, self.cfg.hidden)
 
     def _rope(self, S: int):
+        n = S
+        S = (S + 2047) // 2048 * 2048              # one cached table serves every prompt length up to S; callers get its first n rows
         if S not in self._rope_cache:
             c = self.cfg
             inv = 1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.float32, device=self.device) / c.head_dim))
             ang = torch.arange(S, dtype=torch.float32, device=self.device)[:, None] * inv[None]
             # HF Phi3RotaryEmbedding returns cos / sin cast to the activations' dtype: float32 containers of those values
             self._rope_cache[S] = (ang.cos().to(self.dtype).float().contiguous(), ang.sin().to(self.dtype).float().contiguous())   # (S, hd/2)
-        return self._rope_cache[S]
+        cos, sin = self._rope_cache[S]
+        return cos[:n], sin[:n]
 
     @torch.no_grad()
     def packed_ok(self) -> bool:
@@ -317,7 +320,12 @@ class Phi3Decoder:
         pos = pos_h.to(self.device, non_blocking=True)
         max_len = max(lens)
         cos, sin = self._rope(max_len)
-        return dict(cu=cu, cu_h=cu_h, pos=pos, cos=cos, sin=sin, max_len=max_len, last_rows=(cu[1:] - 1).long(), B=len(lens), Tp=Tp)
+        # one attention-output buffer for all layers (o_proj consumes it before the next layer's attention writes it); its padding rows
+        # are zeroed here, once per prompt batch, instead of once per layer
+        attn_out = torch.empty((Tp, self.cfg.heads, self.cfg.head_dim), dtype=self.dtype, device=self.device)
+        if cu_h[-1] < Tp:
+            attn_out[cu_h[-1]:].zero_()
+        return dict(cu=cu, cu_h=cu_h, pos=pos, cos=cos, sin=sin, max_len=max_len, last_rows=(cu[1:] - 1).long(), B=len(lens), Tp=Tp, attn_out=attn_out)
 
     @torch.no_grad()
     def layer_packed(self, li: int, x: torch.Tensor, ctx, keep_kv: Optional[list] = None, prune: bool = False) -> torch.Tensor:
@@ -333,7 +341,7 @@ class Phi3Decoder:
         if keep_kv is not None:
             keep_kv.append(qkv)
         a = D.attention_packed(qkv.view(Tp, Ht, c.head_dim), c.heads, True, ctx["cu"], ctx["B"], ctx["max_len"], n_valid=ctx["cu_h"][-1],
-                               window=self.SLIDING_WINDOW if ctx["max_len"] > self.SLIDING_WINDOW else 0)
+                               window=self.SLIDING_WINDOW if ctx["max_len"] > self.SLIDING_WINDOW else 0, out=ctx.get("attn_out"))
         a = a.view(Tp, c.heads * c.head_dim)
         if prune:
             a, x = a[ctx["last_rows"]].contiguous(), x[ctx["last_rows"]].contiguous()
