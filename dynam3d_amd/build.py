@@ -27,6 +27,7 @@ HIP_SOURCES = [
     ("gemm_kernels.hip", ["-ffp-contract=fast"]),
     ("attn_kernels.hip", ["-ffp-contract=fast"]),
     ("attn2_kernels.hip", ["-ffp-contract=fast"]),
+    ("attn3_kernels.hip", ["-ffp-contract=fast"]),
     ("decode_kernels.hip", ["-ffp-contract=fast"]),
     ("render_kernels.hip", ["-ffp-contract=off"]),
     ("mlp_kernels.hip", ["-ffp-contract=fast"]),

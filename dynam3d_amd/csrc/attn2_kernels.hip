@@ -80,6 +80,12 @@ __device__ __forceinline__ float pair_sum(float v) {
     return a;
 }
 
+#ifdef D3D_FA_STAMP
+// diagnostics build (tools/attn_barrier_stamps.py): [0] cycles inside the key-tile loops summed over waves, [1] of those, cycles between
+// arriving at a tile's barrier and leaving it, [2] wave-tiles, [3] waves
+__device__ unsigned long long g_fa_stamp[4];
+#endif
+
 template <bool BF16, int HD, bool CAUSAL, int NW>
 __global__ void __launch_bounds__(NW * 64, 2)
 k_flash_attn32(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, int64_t row_stride, int64_t batch_stride, int q_off, int k_off,
@@ -379,13 +385,34 @@ k_flash_attn32(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int
                 }                                                                                                                            \
             }                                                                                                                                \
         }                                                                                                                                    \
+        FA_BAR_STAMP_BEGIN                                                                                                                   \
         __syncthreads();          /* tile t+1 is visible; every wave is done with buffer `cur` */                                            \
+        FA_BAR_STAMP_END                                                                                                                     \
     }
 
+#ifdef D3D_FA_STAMP
+    unsigned long long st_bar = 0, st_b0 = 0;
+    const unsigned long long st_t0 = __builtin_readcyclecounter();
+#define FA_BAR_STAMP_BEGIN st_b0 = __builtin_readcyclecounter();
+#define FA_BAR_STAMP_END st_bar += __builtin_readcyclecounter() - st_b0;
+#else
+#define FA_BAR_STAMP_BEGIN
+#define FA_BAR_STAMP_END
+#endif
     int t = t_first;
     for (; t < t_main; ++t) FA_TILE(false)
     for (; t < n_tiles; ++t) FA_TILE(true)
 #undef FA_TILE
+#undef FA_BAR_STAMP_BEGIN
+#undef FA_BAR_STAMP_END
+#ifdef D3D_FA_STAMP
+    if (lane == 0) {
+        atomicAdd(&g_fa_stamp[0], __builtin_readcyclecounter() - st_t0);
+        atomicAdd(&g_fa_stamp[1], st_bar);
+        atomicAdd(&g_fa_stamp[2], (unsigned long long)(n_tiles - t_first));
+        atomicAdd(&g_fa_stamp[3], 1ull);
+    }
+#endif
     // the row sum of query li lives in lane li (hi = 0), register 0: hand it to the partner lane
     float l_i = lacc[0];
     l_i = pair_sum(hi == 0 ? l_i : 0.f);
@@ -413,6 +440,17 @@ k_flash_attn32(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int
 }  // namespace
 
 extern "C" {
+
+#ifdef D3D_FA_STAMP
+int32_t d3d_fa_stamp_read(unsigned long long* host4, int32_t reset) {
+    if (hipMemcpyFromSymbol(host4, HIP_SYMBOL(g_fa_stamp), 32) != hipSuccess) return D3D_EHIP;
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fa_stamp), z, 32) != hipSuccess) return D3D_EHIP;
+    }
+    return D3D_OK;
+}
+#endif
 
 // Same contract as d3d_flash_attention (attn_kernels.hip) plus `window` (0 = none; > 0: a query attends to the last `window` keys,
 // itself included -- HF sliding-window masking, transformers 4.46 `_prepare_4d_causal_attention_mask_with_cache_position`).

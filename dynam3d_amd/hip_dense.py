@@ -21,6 +21,7 @@ _lib.register("d3d_rope_inplace", [vp, vp, vp, i32, i32, i32, i32, i64, vp, i32,
 _lib.register("d3d_set_attention", [vp, vp, i32, i32, i32, i32, vp, vp])
 _lib.register("d3d_flash_attention", [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp])
 _lib.register("d3d_flash_attention_v2", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, i32, vp])
+_lib.register("d3d_flash_attention_v3", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, i32, vp])
 _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
 _lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
 _lib.register("d3d_decode_attention", [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp])
@@ -229,13 +230,17 @@ class HipDense:
 
     V_TR = True    # True: V transposed by the LDS read inside the kernel (no workspace); False: pre-transposed V^T workspace (A/B, tests)
     ATTN_V2 = os.environ.get("D3D_ATTN_V2", "1") != "0"   # csrc/attn2_kernels.hip (32x32x16 MFMA, double-buffered K/V); False: round 1/2's kernel
+    ATTN_V3 = os.environ.get("D3D_ATTN_V3", "1") != "0"   # csrc/attn3_kernels.hip (v2's arithmetic, LDS-DMA staging, bulk fragment prefetch); needs ATTN_V2
+
+    def _flash_v23(self):
+        return self.lib.d3d_flash_attention_v3 if self.ATTN_V3 else self.lib.d3d_flash_attention_v2
 
     def attention_qkv(self, qkv, n_heads, causal, seq_len=None, window=0):
         """qkv (B,S,3H,hd) contiguous fused projection -> (B,S,H,hd): flash attention straight off the projection buffer."""
         B, S, Ht, hd = qkv.shape
         out = torch.empty((B, S, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
         if self.ATTN_V2:
-            _lib.check(self.lib.d3d_flash_attention_v2(_p(qkv), _p(out), B, S, n_heads, hd, Ht * hd, S * Ht * hd, 0, n_heads, 2 * n_heads, 1 if causal else 0,
+            _lib.check(self._flash_v23()(_p(qkv), _p(out), B, S, n_heads, hd, Ht * hd, S * Ht * hd, 0, n_heads, 2 * n_heads, 1 if causal else 0,
                                                        S if seq_len is None else seq_len, None, window, 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
             return out
         if window:
@@ -260,7 +265,7 @@ class HipDense:
             if n_valid < T:
                 out[n_valid:].zero_()
         if self.ATTN_V2:
-            _lib.check(self.lib.d3d_flash_attention_v2(_p(qkv), _p(out), n_seq, max_len, n_heads, hd, Ht * hd, 0, 0, n_heads, 2 * n_heads, 1 if causal else 0,
+            _lib.check(self._flash_v23()(_p(qkv), _p(out), n_seq, max_len, n_heads, hd, Ht * hd, 0, 0, n_heads, 2 * n_heads, 1 if causal else 0,
                                                        max_len, _p(cu_seqlens), window, 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
             return out
         if window:

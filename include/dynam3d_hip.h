@@ -371,6 +371,11 @@ int32_t d3d_flash_attention_v2(const void* qkv_d, void* out_d, int32_t B, int32_
                                int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
                                const int32_t* cu_seqlens_d /* optional (B+1): packed variable-length batch */, int32_t window, int32_t dtype,
                                void* stream);
+/* Same contract and results layout as d3d_flash_attention_v2; K/V tiles staged by LDS-DMA (no VGPR round trip) and all fragment reads of a
+ * tile issued a phase ahead (csrc/attn3_kernels.hip).  The host's default (D3D_ATTN=2 / 1 select the older kernels for A/B runs). */
+int32_t d3d_flash_attention_v3(const void* qkv_d, void* out_d, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride,
+                               int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
+                               const int32_t* cu_seqlens_d, int32_t window, int32_t dtype, void* stream);
 /* self-attention inside packed variable-length token sets (set encoders VLN-FF:134-155): float32, head_dim 64.
  * qkv (T, 3*H*64) = [q|k|v]; set g = tokens [set_off[g], set_off[g+1]); q_rows > 0 restricts the queries to the
  * first q_rows rows of every set (1 = CLS only).  out (T, H*64); rows that are not queried are left untouched. */

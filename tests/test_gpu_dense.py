@@ -256,7 +256,7 @@ def test_set_attention_varlen(hd):
             assert float(cls[off[g] + 1:off[g + 1]].abs().sum()) == 0.0
 
 
-ATTN_VARIANTS = {"v2": (True, True), "v1_tr": (False, True), "v1_workspace": (False, False)}      # (ATTN_V2, V_TR)
+ATTN_VARIANTS = {"v3": (True, True, True), "v2": (True, True, False), "v1_tr": (False, True, False), "v1_workspace": (False, False, False)}      # (ATTN_V2, V_TR, ATTN_V3)
 
 
 @pytest.mark.parametrize("variant", list(ATTN_VARIANTS))
@@ -267,6 +267,7 @@ def test_flash_attention_vs_fp32_reference(hd, dt, tol, variant, monkeypatch):
     ds_read_b64_tr_b16 / through a pre-transposed V^T workspace."""
     monkeypatch.setattr(type(hd), "ATTN_V2", ATTN_VARIANTS[variant][0])
     monkeypatch.setattr(type(hd), "V_TR", ATTN_VARIANTS[variant][1])
+    monkeypatch.setattr(type(hd), "ATTN_V3", ATTN_VARIANTS[variant][2])
     torch.manual_seed(4)
     for (B, H, S, d, causal) in [(2, 3, 577, 64, False), (2, 4, 900, 96, True), (1, 2, 130, 96, True), (3, 2, 64, 64, True), (1, 1, 1, 96, True), (2, 2, 333, 96, False)]:
         qkv = (torch.randn(B, S, 3 * H, d, device="cuda") * 1.5).to(dt)
@@ -294,6 +295,7 @@ def test_flash_attention_packed_ragged(hd, dt, tol, causal, variant, monkeypatch
     rows after the last sequence.  Reference: fp32 softmax attention per sequence.  Tolerance = 16-bit output rounding + 16-bit P."""
     monkeypatch.setattr(type(hd), "ATTN_V2", ATTN_VARIANTS[variant][0])
     monkeypatch.setattr(type(hd), "V_TR", ATTN_VARIANTS[variant][1])
+    monkeypatch.setattr(type(hd), "ATTN_V3", ATTN_VARIANTS[variant][2])
     torch.manual_seed(5)
     H, d = 4, 96
     lens = [1, 63, 128, 129, 200, 385, 640, 705]
@@ -320,6 +322,7 @@ def test_flash_attention_bitwise_repeatable(hd, dt, variant, monkeypatch):
     asm -- and the last bits of every query block after the first changed from launch to launch while every tolerance test passed.)"""
     monkeypatch.setattr(type(hd), "ATTN_V2", ATTN_VARIANTS[variant][0])
     monkeypatch.setattr(type(hd), "V_TR", ATTN_VARIANTS[variant][1])
+    monkeypatch.setattr(type(hd), "ATTN_V3", ATTN_VARIANTS[variant][2])
     torch.manual_seed(9)
     for H, d, lens in ((32, 96, [37, 211, 129, 64, 5, 90, 300, 17]), (8, 96, [828, 826, 1072]), (16, 64, [577, 577])):
         T = sum(lens)

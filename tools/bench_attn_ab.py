@@ -1,4 +1,5 @@
-"""A/B of the two flash-attention kernels inside one process: v1 (16x16x32, attn_kernels.hip) / v2 (32x32x16, attn2_kernels.hip), alternating,
+"""A/B of the flash-attention kernels inside one process: v1 (16x16x32, attn_kernels.hip) / v2 (32x32x16, attn2_kernels.hip) / v3 (v2 + LDS-DMA +
+bulk fragment prefetch, attn3_kernels.hip), alternating,
 at the step's own shapes: Phi-3 packed causal (hd 96, bf16) and the ViT towers (8 x 577, 16 heads, hd 64, fp16 / bf16)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,11 +17,13 @@ def timeit(fn, n=40):
 def ab(fn, label, flops):
     res = {}
     for rnd in range(2):
-        for v2 in (False, True):
-            HipDense.ATTN_V2 = v2
-            res.setdefault(v2, []).append(timeit(fn))
-    t1, t2 = min(res[False]), min(res[True])
-    print(f"{label}: v1 {t1:.1f} us ({flops / t1 / 1e6:.0f} TF/s)   v2 {t2:.1f} us ({flops / t2 / 1e6:.0f} TF/s)   x{t1 / t2:.2f}   rounds v1 {np.round(res[False], 1)} v2 {np.round(res[True], 1)}", flush=True)
+        for name, v2, v3 in (("v1", False, False), ("v2", True, False), ("v3", True, True)):
+            HipDense.ATTN_V2, HipDense.ATTN_V3 = v2, v3
+            res.setdefault(name, []).append(timeit(fn))
+    HipDense.ATTN_V2 = HipDense.ATTN_V3 = True
+    t = {k: min(v) for k, v in res.items()}
+    print(f"{label}: " + "   ".join(f"{k} {t[k]:.1f} us ({flops / t[k] / 1e6:.0f} TF/s)" for k in t) + f"   v3/v2 x{t['v2'] / t['v3']:.2f}   rounds " +
+          " ".join(f"{k} {np.round(res[k], 1)}" for k in res), flush=True)
 H, d = 32, 96
 for lens in ([828, 826, 1072, 800, 1012, 753, 766, 769], [755, 835, 946, 744, 938, 766, 761, 729], [900] * 8, [1024] * 8):
     T = sum(lens); Tp = (T + 255) // 256 * 256
