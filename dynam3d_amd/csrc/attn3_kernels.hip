@@ -236,12 +236,17 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
     const int kmax = CAUSAL ? min(qrow, seq_len - 1) : seq_len - 1;
     const int kmin = window > 0 ? qrow - window + 1 : 0;
 
-    // row sums on the matrix pipe (attn2_kernels.hip): an A fragment whose row 0 is all ones
+    // Row sums.  head_dim 64 has registers to spare: on the matrix pipe (attn2_kernels.hip: an A fragment whose row 0 is all ones puts
+    // sum_k P[k][q] into row 0 of `lacc`, 4 extra MFMAs per tile, no VALU).  head_dim 96 is at the 256-register limit: there the 16
+    // accumulator registers of that trick spilled (18 VGPRs in the tile loop), so each lane adds its 32 values (pairwise tree, float32,
+    // before P is rounded) -- 78 -> 74 us per Phi-3 launch in spite of the extra VALU work.
+    constexpr bool MFMA_SUM = HD == 64;
     const uint32_t one2 = BF16 ? 0x3F803F80u : 0x3C003C00u;
     const uint4 ones = (lane & 31) == 0 ? make_uint4(one2, one2, one2, one2) : make_uint4(0, 0, 0, 0);
     float16v lacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+    float l_i = 0.f;                         // (VALU variant) this lane's half of the row sum: its 32 of the 64 keys of every tile
 
     // every wave is past the previous pass's last barrier: both buffers are free
     request_tile(t_first, 0);
@@ -328,12 +333,20 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
                 const float alpha = __builtin_amdgcn_exp2f(m_i - m_use);                                                                     \
                 _Pragma("unroll") for (int d = 0; d < DB; ++d)                                                                               \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;                                                          \
-                lacc[0] *= alpha;                                                                                                            \
+                if (MFMA_SUM) lacc[0] *= alpha; else l_i *= alpha;                                                                           \
             }                                                                                                                                \
             m_i = m_new;                                                                                                                     \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) st0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st0[r], scale_log2e, -m_use));     \
             if (blk1_on) {                                                                                                                   \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) st1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st1[r], scale_log2e, -m_use)); \
+            }                                                                                                                                \
+            if (!MFMA_SUM) {   /* row sum: pairwise tree, 16 + 16 values */                                                                  \
+                float ts = 0.f;                                                                                                              \
+                _Pragma("unroll") for (int r = 0; r < 16; r += 4) ts += (st0[r] + st0[r + 1]) + (st0[r + 2] + st0[r + 3]);                   \
+                if (blk1_on) {                                                                                                               \
+                    _Pragma("unroll") for (int r = 0; r < 16; r += 4) ts += (st1[r] + st1[r + 1]) + (st1[r + 2] + st1[r + 3]);               \
+                }                                                                                                                            \
+                l_i += ts;                                                                                                                   \
             }                                                                                                                                \
             /* P^T fragments: MFMA step s covers keys 16s .. 16s+15 of the tile; k-slot (hi*8 + jj*4 + r) = key 16s + 8jj + 4hi + r */       \
             uint4 pf[4];                                                                                                                     \
@@ -347,15 +360,15 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
                 pf[2 + s].z = pack2<BF16>(st1[8 * s + 4], st1[8 * s + 5]);                                                                   \
                 pf[2 + s].w = pack2<BF16>(st1[8 * s + 6], st1[8 * s + 7]);                                                                   \
             }                                                                                                                                \
-            /* ---- O^T += V^T P^T (+ the row sums) out of registers -------------------------------------------------------------------- */  \
+            /* ---- O^T += V^T P^T out of registers --------------- -------------------------------------------------------------------- */  \
             _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                                  \
                 _Pragma("unroll") for (int d = 0; d < DB; ++d) oacc[d] = mfma32<BF16>(vf[s][d], pf[s], oacc[d]);                             \
-                lacc = mfma32<BF16>(ones, pf[s], lacc);                                                                                      \
+                if (MFMA_SUM) lacc = mfma32<BF16>(ones, pf[s], lacc);                                                                        \
             }                                                                                                                                \
             if (blk1_on) {                                                                                                                   \
                 _Pragma("unroll") for (int s = 2; s < 4; ++s) {                                                                              \
                     _Pragma("unroll") for (int d = 0; d < DB; ++d) oacc[d] = mfma32<BF16>(vf[s][d], pf[s], oacc[d]);                         \
-                    lacc = mfma32<BF16>(ones, pf[s], lacc);                                                                                  \
+                    if (MFMA_SUM) lacc = mfma32<BF16>(ones, pf[s], lacc);                                                                    \
                 }                                                                                                                            \
             }                                                                                                                                \
         }                                                                                                                                    \
@@ -367,9 +380,8 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
     for (; t < t_main; ++t) FA_TILE(false)
     for (; t < n_tiles; ++t) FA_TILE(true)
 #undef FA_TILE
-    // the row sum of query li lives in lane li (hi = 0), register 0: hand it to the partner lane
-    float l_i = lacc[0];
-    l_i = pair_sum(hi == 0 ? l_i : 0.f);
+    // MFMA variant: the row sum of query li lives in lane li (hi = 0), register 0; VALU variant: the two lanes of a query hold its two halves
+    l_i = pair_sum(MFMA_SUM ? (hi == 0 ? lacc[0] : 0.f) : l_i);
     // ---- epilogue: lane holds O[qrow][32d + 8j + 4hi + r]; lane pairs exchange so that each stores 16 contiguous bytes ---------------------
     const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
     uint16_t* op = out + ((row0 + qrow) * H + h) * HD;
