@@ -241,10 +241,13 @@ def main():
             # Fabric-side bytes per launch of this kernel: counters cannot be read inside an un-profiled run, so this is the figure of THIS
             # ROUND's rocprofv3 --pmc passes over the same kernel (profiles/rNN_pmc_gate_up.json: 2 * FETCH_SIZE + WRITE_SIZE, separate
             # passes; FETCH_SIZE counts 128-B requests at 64 B on gfx950, MI355X_MICROARCH.md), scaled by the rows of this run.
-            pm = json.load(open(pj))
-            traffic = int(pm["hbm_bytes_per_launch"] * rows_gemm / float(pm["rows"]))
-            traffic_note = ("from_profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, the kernel at M = %d), "
-                            "scaled by launched rows; includes Infinity-Cache hits (algorithmic bytes %d)" % (os.path.basename(pj), pm["rows"], int(pm["algorithmic_bytes"] * rows_gemm / float(pm["rows"]))))
+            try:
+                pm = json.load(open(pj))
+                traffic = int(pm["hbm_bytes_per_launch"] * rows_gemm / float(pm["rows"]))
+                traffic_note = ("from_profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, the kernel at M = %d), "
+                                "scaled by launched rows; includes Infinity-Cache hits (algorithmic bytes %d)" % (os.path.basename(pj), pm["rows"], int(pm["algorithmic_bytes"] * rows_gemm / float(pm["rows"]))))
+            except (KeyError, ValueError, OSError) as e:            # a profile file that lacks the fields is reported, it does not stop the benchmark
+                traffic, traffic_note = None, "profiles/%s unusable (%s: %s)" % (os.path.basename(pj), type(e).__name__, e)
         out = {
             "metric": "nav steps/sec (RGB-D obs->action logits) at batch=8", "value": round(B * a.steps * a.gpus / dt, 3), "unit": "env-steps/s",
             "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
