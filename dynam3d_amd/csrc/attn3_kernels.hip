@@ -56,6 +56,22 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     }
 }
 
+template <bool BF16>
+__device__ __forceinline__ float ld16(uint16_t v) {
+    if constexpr (BF16) return __uint_as_float((uint32_t)v << 16);
+    else return __half2float(*reinterpret_cast<const __half*>(&v));
+}
+template <bool BF16>
+__device__ __forceinline__ uint16_t st16(float f) {
+    if constexpr (BF16) {
+        const __bf16 r = (__bf16)f;                  // hardware converter: round to nearest even, NaN-safe
+        return *reinterpret_cast<const uint16_t*>(&r);
+    } else {
+        __half h = __float2half_rn(f);
+        return *reinterpret_cast<uint16_t*>(&h);
+    }
+}
+
 // (builtins, not inline asm: an asm statement hides its VALU reads from the hazard recogniser -- see attn2_kernels.hip)
 __device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
@@ -94,7 +110,8 @@ __device__ __forceinline__ void dma_piece(uint32_t voff, const void* base, uint3
 template <bool BF16, int HD, bool CAUSAL>
 __global__ void __launch_bounds__(NT, 2)
 k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, int64_t row_stride, int64_t batch_stride, int q_off, int k_off,
-                 int v_off, float scale_log2e, int seq_len, const int32_t* __restrict__ cu, int n_qblocks, int window, int nx, int B) {
+                 int v_off, float scale_log2e, int seq_len, const int32_t* __restrict__ cu, int n_qblocks, int window, int nx, int B,
+                 const float* __restrict__ rope_cos, const float* __restrict__ rope_sin) {
     constexpr int KS = HD / 16;              // 16-deep MFMA steps over head_dim (QK^T)
     constexpr int DB = HD / 32;              // 32-wide head-dim blocks (PV)
     constexpr int CH = HD / 8;               // 16-byte chunks per row
@@ -222,6 +239,32 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
         const int q = qrow < S ? qrow : S - 1;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(Qp + (int64_t)q * row_stride + ks * 16 + hi * 8);
+        // Rotary embedding of the queries, fused (the buffer holds un-rotated q; k was rotated in place by d3d_rope_inplace).  Half-split
+        // RoPE pairs dim d with d + head_dim / 2 = fragment ks with fragment ks + KS / 2 of the SAME lane; position = the query's row in its
+        // sequence.  Arithmetic = dense_kernels.hip k_rope (HF apply_rotary_pos_emb on 16-bit tensors: every product and the sum stored
+        // 16-bit), so the fused and the separate path give the same bits.
+        if (rope_cos) {
+            constexpr int HALF = HD / 2;
+#pragma unroll
+            for (int ks = 0; ks < KS / 2; ++ks) {
+                const float* cp = rope_cos + (int64_t)q * HALF + ks * 16 + hi * 8;
+                const float* sp = rope_sin + (int64_t)q * HALF + ks * 16 + hi * 8;
+                const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+                const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+                const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                const uint16_t* ah = reinterpret_cast<const uint16_t*>(&qf[ks]);
+                const uint16_t* bh = reinterpret_cast<const uint16_t*>(&qf[ks + KS / 2]);
+                uint16_t o1[8], o2[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x1 = ld16<BF16>(ah[j]), x2 = ld16<BF16>(bh[j]);
+                    o1[j] = st16<BF16>(ld16<BF16>(st16<BF16>(x1 * cc[j])) - ld16<BF16>(st16<BF16>(x2 * ss[j])));
+                    o2[j] = st16<BF16>(ld16<BF16>(st16<BF16>(x2 * cc[j])) + ld16<BF16>(st16<BF16>(x1 * ss[j])));
+                }
+                qf[ks] = *reinterpret_cast<const uint4*>(o1);
+                qf[ks + KS / 2] = *reinterpret_cast<const uint4*>(o2);
+            }
+        }
     }
     float16v oacc[DB];
 #pragma unroll
@@ -403,10 +446,23 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
 
 extern "C" {
 
+// d3d_flash_attention_v3 + the queries' rotary embedding: the buffer holds UN-ROTATED q (and rotated k); rope_cos / rope_sin are the
+// (positions, head_dim / 2) float32 tables of d3d_rope_inplace, a query's position is its row inside its sequence.
+int32_t d3d_flash_attention_v3_rope_q(const void* qkv, void* out, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride, int64_t batch_stride,
+                                      int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len, const int32_t* cu_seqlens,
+                                      int32_t window, const float* rope_cos, const float* rope_sin, int32_t dtype, void* stream);
+
 // Same contract as d3d_flash_attention_v2 (attn2_kernels.hip); 128 query rows per workgroup.
 int32_t d3d_flash_attention_v3(const void* qkv, void* out, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride, int64_t batch_stride,
                                int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len, const int32_t* cu_seqlens, int32_t window,
                                int32_t dtype, void* stream) {
+    return d3d_flash_attention_v3_rope_q(qkv, out, B, S, H, head_dim, row_stride, batch_stride, q_off, k_off, v_off, causal, seq_len, cu_seqlens, window,
+                                         nullptr, nullptr, dtype, stream);
+}
+
+int32_t d3d_flash_attention_v3_rope_q(const void* qkv, void* out, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride, int64_t batch_stride,
+                                      int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len, const int32_t* cu_seqlens,
+                                      int32_t window, const float* rope_cos, const float* rope_sin, int32_t dtype, void* stream) {
     if (B <= 0 || S <= 0) return D3D_OK;
     if ((head_dim != 64 && head_dim != 96) || (row_stride & 7) || (batch_stride & 7) || window < 0 || (window > 0 && !causal)) {
         d3d_set_error_("d3d_flash_attention_v3: head_dim must be 64 or 96; strides multiples of 8 elements; a window needs causal");
@@ -414,6 +470,10 @@ int32_t d3d_flash_attention_v3(const void* qkv, void* out, int32_t B, int32_t S,
     }
     if ((int64_t)BKV * row_stride * 2 >= (1ll << 31)) {
         d3d_set_error_("d3d_flash_attention_v3: a 64-row tile of the QKV buffer must span less than 2 GiB (32-bit per-lane offsets)");
+        return D3D_EINVAL;
+    }
+    if ((rope_cos == nullptr) != (rope_sin == nullptr)) {
+        d3d_set_error_("d3d_flash_attention_v3_rope_q: rope_cos and rope_sin come together");
         return D3D_EINVAL;
     }
     const float sl2 = 1.4426950408889634f / sqrtf((float)head_dim);
@@ -425,7 +485,7 @@ int32_t d3d_flash_attention_v3(const void* qkv, void* out, int32_t B, int32_t S,
     const int nx = causal ? (nqb + 1) / 2 : nqb;
     dim3 grid((unsigned)((int64_t)nx * H * B)), block(NT);
 #define D3D_FA3(BF, HDV, CA) hipLaunchKernelGGL((k_flash_attn_dma<BF, HDV, CA>), grid, block, 0, s, q, o, S, H, row_stride, batch_stride, q_off, k_off, v_off, \
-                                                sl2, seq_len, cu_seqlens, nqb, window, nx, B)
+                                                sl2, seq_len, cu_seqlens, nqb, window, nx, B, rope_cos, rope_sin)
     if (dtype == 0) {
         if (head_dim == 96) { if (causal) D3D_FA3(true, 96, true); else D3D_FA3(true, 96, false); }
         else { if (causal) D3D_FA3(true, 64, true); else D3D_FA3(true, 64, false); }

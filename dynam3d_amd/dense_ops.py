@@ -184,9 +184,14 @@ def rope_packed_(qkv2d: torch.Tensor, n_rot_heads: int, head_dim: int, cos, sin,
 
 
 def attention_packed(qkv3: torch.Tensor, n_heads: int, causal: bool, cu_seqlens: torch.Tensor, n_seq: int, max_len: int, n_valid=None, window: int = 0,
-                     out=None):
+                     out=None, rope_q=None):
+    """`rope_q` = (cos, sin): the buffer's queries are NOT rotated yet, the kernel rotates them (see `can_fuse_rope_q`)."""
     _hit("attention")
-    return _hip.attention_packed(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid, window, out)
+    return _hip.attention_packed(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid, window, out, rope_q)
+
+
+def can_fuse_rope_q() -> bool:
+    return BACKEND["attention"] == "hip" and BACKEND["rope"] == "hip" and _hip is not None and _hip.can_fuse_rope_q()
 
 
 def decode_attention(qkv_new, prompt_qkv, cu_seqlens, knew, vnew, n_heads: int, t_new: int, max_prompt_len: int, rope=None):

@@ -22,6 +22,7 @@ _lib.register("d3d_set_attention", [vp, vp, i32, i32, i32, i32, vp, vp])
 _lib.register("d3d_flash_attention", [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp])
 _lib.register("d3d_flash_attention_v2", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, i32, vp])
 _lib.register("d3d_flash_attention_v3", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, i32, vp])
+_lib.register("d3d_flash_attention_v3_rope_q", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp])
 _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
 _lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
 _lib.register("d3d_decode_attention", [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp])
@@ -251,7 +252,11 @@ class HipDense:
                                                 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
         return out
 
-    def attention_packed(self, qkv, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid=None, window=0, out=None):
+    def can_fuse_rope_q(self):
+        """The v3 attention kernel can rotate the queries itself (d3d_flash_attention_v3_rope_q)."""
+        return self.ATTN_V2 and self.ATTN_V3
+
+    def attention_packed(self, qkv, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid=None, window=0, out=None, rope_q=None):
         """PACKED variable-length batch: qkv (T, 3H, hd) rows of sequence b = [cu[b], cu[b+1]) -> (T, H, hd).  Rows beyond
         cu[-1] (padding of the packed buffer) come back zero; `n_valid` = cu[-1] as a host int saves zero-filling the rest.
         `out`: a caller-owned (T, H, hd) buffer whose padding rows are already zero (the kernel writes rows < cu[-1] only)."""
@@ -264,6 +269,16 @@ class HipDense:
             out = torch.empty((T, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
             if n_valid < T:
                 out[n_valid:].zero_()
+        if rope_q is not None:
+            if not self.can_fuse_rope_q():
+                raise RuntimeError("attention_packed(rope_q=...) needs the v3 kernel (D3D_ATTN_V2 / D3D_ATTN_V3 not disabled)")
+            cos, sin = rope_q                                     # (positions >= max_len, hd / 2) float32, contiguous
+            assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
+            assert cos.shape[0] >= max_len and cos.shape[1] == hd // 2 and sin.shape == cos.shape
+            _lib.check(self.lib.d3d_flash_attention_v3_rope_q(_p(qkv), _p(out), n_seq, max_len, n_heads, hd, Ht * hd, 0, 0, n_heads, 2 * n_heads,
+                                                              1 if causal else 0, max_len, _p(cu_seqlens), window, _p(cos), _p(sin),
+                                                              0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
+            return out
         if self.ATTN_V2:
             _lib.check(self._flash_v23()(_p(qkv), _p(out), n_seq, max_len, n_heads, hd, Ht * hd, 0, 0, n_heads, 2 * n_heads, 1 if causal else 0,
                                                        max_len, _p(cu_seqlens), window, 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))

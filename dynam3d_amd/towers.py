@@ -15,6 +15,7 @@ Weights arrive under the reference checkpoints' own key names (OpenAI CLIP `visu
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -327,6 +328,9 @@ class Phi3Decoder:
             attn_out[cu_h[-1]:].zero_()
         return dict(cu=cu, cu_h=cu_h, pos=pos, cos=cos, sin=sin, max_len=max_len, last_rows=(cu[1:] - 1).long(), B=len(lens), Tp=Tp, attn_out=attn_out)
 
+    # rotate the queries inside the attention kernel (d3d_flash_attention_v3_rope_q) when the backend can; D3D_FUSE_ROPE_Q=0: in place, with the keys
+    FUSE_ROPE_Q = os.environ.get("D3D_FUSE_ROPE_Q", "1") != "0"
+
     @torch.no_grad()
     def layer_packed(self, li: int, x: torch.Tensor, ctx, keep_kv: Optional[list] = None, prune: bool = False) -> torch.Tensor:
         """One decoder layer over the packed rows x (Tp, hidden) -> (Tp, hidden) (HF `Phi3DecoderLayer.forward`: RMSNorm, fused QKV,
@@ -337,11 +341,17 @@ class Phi3Decoder:
         Tp, Ht = x.shape[0], c.heads + 2 * c.kv_heads
         h = D.rms_norm(x, L["n1"], c.rms_eps)
         qkv = D.linear(h, L["qkv_w"], None)
-        D.rope_packed_(qkv, c.heads + c.kv_heads, c.head_dim, ctx["cos"], ctx["sin"], ctx["pos"])
+        fuse_q = self.FUSE_ROPE_Q and D.can_fuse_rope_q()
+        if fuse_q:
+            # keys rotated in place (the KV cache keeps rotated keys), queries rotated inside the attention kernel: half of k_rope's traffic
+            D.rope_packed_(qkv[:, c.heads * c.head_dim:], c.kv_heads, c.head_dim, ctx["cos"], ctx["sin"], ctx["pos"])
+        else:
+            D.rope_packed_(qkv, c.heads + c.kv_heads, c.head_dim, ctx["cos"], ctx["sin"], ctx["pos"])
         if keep_kv is not None:
-            keep_kv.append(qkv)
+            keep_kv.append(qkv)                                        # (only its k / v heads are read afterwards)
         a = D.attention_packed(qkv.view(Tp, Ht, c.head_dim), c.heads, True, ctx["cu"], ctx["B"], ctx["max_len"], n_valid=ctx["cu_h"][-1],
-                               window=self.SLIDING_WINDOW if ctx["max_len"] > self.SLIDING_WINDOW else 0, out=ctx.get("attn_out"))
+                               window=self.SLIDING_WINDOW if ctx["max_len"] > self.SLIDING_WINDOW else 0, out=ctx.get("attn_out"),
+                               rope_q=(ctx["cos"], ctx["sin"]) if fuse_q else None)
         a = a.view(Tp, c.heads * c.head_dim)
         if prune:
             a, x = a[ctx["last_rows"]].contiguous(), x[ctx["last_rows"]].contiguous()

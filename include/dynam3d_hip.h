@@ -376,6 +376,13 @@ int32_t d3d_flash_attention_v2(const void* qkv_d, void* out_d, int32_t B, int32_
 int32_t d3d_flash_attention_v3(const void* qkv_d, void* out_d, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride,
                                int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
                                const int32_t* cu_seqlens_d, int32_t window, int32_t dtype, void* stream);
+/* The same with the QUERIES' rotary embedding fused: the buffer holds un-rotated q and rotated k (d3d_rope_inplace over the k heads only);
+ * rope_cos_d / rope_sin_d are d3d_rope_inplace's (positions, head_dim / 2) float32 tables, a query's position = its row inside its sequence.
+ * Same bits as rotating q in place first.  Both null = d3d_flash_attention_v3. */
+int32_t d3d_flash_attention_v3_rope_q(const void* qkv_d, void* out_d, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride,
+                                      int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
+                                      const int32_t* cu_seqlens_d, int32_t window, const float* rope_cos_d, const float* rope_sin_d, int32_t dtype,
+                                      void* stream);
 /* self-attention inside packed variable-length token sets (set encoders VLN-FF:134-155): float32, head_dim 64.
  * qkv (T, 3*H*64) = [q|k|v]; set g = tokens [set_off[g], set_off[g+1]); q_rows > 0 restricts the queries to the
  * first q_rows rows of every set (1 = CLS only).  out (T, H*64); rows that are not queried are left untouched. */

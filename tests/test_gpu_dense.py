@@ -334,6 +334,33 @@ def test_flash_attention_bitwise_repeatable(hd, dt, variant, monkeypatch):
                 assert torch.equal(hd.attention_packed(qkv, H, causal, cu, len(lens), max(lens)), first), (H, d, lens, causal)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_flash_attention_fused_query_rope_equals_separate_rope(hd, dt):
+    """d3d_flash_attention_v3_rope_q (un-rotated q in the buffer, rotated inside the kernel; k rotated in place) == d3d_rope_inplace over
+    q and k followed by d3d_flash_attention_v3, bit for bit: packed ragged prompts, head_dim 96 and 64, with and without the window."""
+    torch.manual_seed(12)
+    for H, d, lens, window in ((8, 96, [1, 63, 129, 200, 385, 705], 0), (4, 64, [300, 77], 0), (2, 96, [700, 40], 257)):
+        T = sum(lens)
+        Tp = (T + 255) // 256 * 256
+        qkv = (torch.randn(Tp, 3 * H * d, device="cuda") * 0.8).to(dt)
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+        pos = torch.zeros(Tp, dtype=torch.int32, device="cuda")
+        for b, n in enumerate(lens):
+            pos[int(cu[b]):int(cu[b]) + n] = torch.arange(n, dtype=torch.int32, device="cuda")
+        S = max(lens)
+        inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32, device="cuda") / d))
+        ang = torch.arange(S + 5, dtype=torch.float32, device="cuda")[:, None] * inv[None]
+        cos, sin = ang.cos().to(dt).float().contiguous(), ang.sin().to(dt).float().contiguous()
+        a = qkv.clone()
+        hd.rope_inplace(a, cos, sin, 1, 2 * H, d, pos)                                  # q and k heads
+        ref = hd.attention_packed(a.view(Tp, 3 * H, d), H, True, cu, len(lens), S, n_valid=T, window=window)
+        b_ = qkv.clone()
+        hd.rope_inplace(b_[:, H * d:], cos, sin, 1, H, d, pos)                           # k heads only
+        assert torch.equal(b_[:, H * d:], a[:, H * d:]) and torch.equal(b_[:, :H * d], qkv[:, :H * d])
+        out = hd.attention_packed(b_.view(Tp, 3 * H, d), H, True, cu, len(lens), S, n_valid=T, window=window, rope_q=(cos, sin))
+        assert torch.equal(out, ref), (H, d, lens, window, float((out.float() - ref.float()).abs().max()))
+
+
 def test_flash_attention_sliding_window(hd):
     """The v2 kernel's sliding window (HF Phi-3-mini-4k: a query attends to its last `window` keys, itself included): packed ragged
     prompts longer than the window and a dense batch, windows that cut inside a tile / at a tile edge / before the first query block,
