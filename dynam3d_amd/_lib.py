@@ -80,3 +80,11 @@ def load() -> C.CDLL:
 def check(rc: int):
     if rc != 0:
         raise RuntimeError(f"libdynam3d_hip: {_lib.d3d_last_error().decode()} (code {rc})")
+
+
+def current_stream_ptr():
+    """The current HIP stream of the current device as a ctypes void pointer.  `torch.cuda.current_stream().cuda_stream` builds a Python
+    Stream object through four layers of device-index helpers (~8 us); a step makes ~400 launches, and the 3D-token update's launches
+    are a latency chain on the host.  The raw getters are two C calls."""
+    import torch
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))

@@ -26,7 +26,7 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.current_stream_ptr()
 
 
 class F32Ops:

@@ -172,6 +172,20 @@ class Feature_Fields:
     def _i32(self, a) -> torch.Tensor:
         return torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(self.device, non_blocking=True)
 
+    def _i32_many(self, *arrays):
+        """Several int32 index arrays in ONE host-to-device copy (every small upload is ~15 us of host time on the update's latency
+        chain): returns device views, each starting on a 16-byte boundary."""
+        arrs = [np.ascontiguousarray(a, np.int32).reshape(-1) for a in arrays]
+        offs, n = [], 0
+        for a in arrs:
+            offs.append(n)
+            n += (a.size + 3) // 4 * 4
+        buf = np.zeros(max(n, 4), np.int32)
+        for a, o in zip(arrs, offs):
+            buf[o:o + a.size] = a
+        dev = torch.from_numpy(buf).to(self.device, non_blocking=True)
+        return [dev[o:o + a.size] for a, o in zip(arrs, offs)]
+
     def _f32(self, a) -> torch.Tensor:
         return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device, non_blocking=True)
 
@@ -357,7 +371,7 @@ class Feature_Fields:
             pools = self.pools
             rb, k0, has_tree = zip(*[st.begin_view(e) for e in envs])
             k0 = [k if t else 0 for k, t in zip(k0, has_tree)]
-            row_base = self._i32(rb)
+            row_base = self._i32(rb)        # (re-bound below to a slice of this view's one index upload)
             if pinhole:                                                                                   # PRE-FF:905-916
                 cams = pinhole_unproject_rows([_host(batch_camera_intrinsic[e][ix]) for e in envs], [_host(batch_rot[e][ix]) for e in envs],
                                               [_host(batch_trans[e][ix]) for e in envs], scale_tan, depth_scale, depth_trunc)
@@ -381,9 +395,11 @@ class Feature_Fields:
             tok_row = (np.asarray(rb, np.int32)[:, None] + order).reshape(-1).astype(np.int32)
             grp_off = np.concatenate([[0], np.cumsum(counts.reshape(-1))]).astype(np.int32)
             G = len(envs) * n_max
-            centroid, cell, geom7 = ops.group_stats7(pools, self._i32(tok_slot), self._i32(tok_row), self._i32(grp_off), G, self.cell_len)
-            tok_fts = ops.gather_fts(pools, self._i32(tok_slot), self._i32(tok_row))
             valid_g = np.nonzero(counts.reshape(-1) > 0)[0]
+            tok_slot_d, tok_row_d, grp_off_d, valid_g_d, n_seg_d, k0_d, tree_slots_d = self._i32_many(tok_slot, tok_row, grp_off, valid_g, n_seg, k0,
+                                                                                                    self._tree_slots)
+            centroid, cell, geom7 = ops.group_stats7(pools, tok_slot_d, tok_row_d, grp_off_d, G, self.cell_len)
+            tok_fts = ops.gather_fts(pools, tok_slot_d, tok_row_d)
             if trainer is not None:                                           # differentiable encoding + loss terms of this view (PRE-FF:940-1008)
                 img_ix = img_mean = None
                 if batch_image_ft is not None:
@@ -393,13 +409,12 @@ class Feature_Fields:
             else:
                 new_fts_valid = self.dense.encode_patch_sets(tok_fts, geom7, counts.reshape(-1)[valid_g])
             new_fts = torch.zeros((G, FTS), dtype=torch.float32, device=self.device)
-            new_fts.index_copy_(0, torch.from_numpy(valid_g).to(self.device), new_fts_valid)
+            new_fts.index_copy_(0, valid_g_d.long(), new_fts_valid)
 
             # ---- KNN proposals + merge discriminator (VLN-FF:604-621) ------------------------------
             ident = all(self.slots[e] == e for e in envs)
             tree_pts = pools.tree_pos if ident else pools.tree_pos.index_select(0, slot.long()).contiguous()
-            d2, idx = ops.knn(tree_pts, pools.m_cap * 3, self._i32(self._tree_slots), centroid, n_max * 3,
-                              self._i32(n_seg), self._i32(k0), len(envs), n_max, k_max)
+            d2, idx = ops.knn(tree_pts, pools.m_cap * 3, tree_slots_d, centroid, n_max * 3, n_seg_d, k0_d, len(envs), n_max, k_max)
             pair_e, pair_s, pair_j = [], [], []
             for j_, e in enumerate(envs):
                 if k0[j_] > 0:
@@ -407,13 +422,13 @@ class Feature_Fields:
                     pair_e.append(np.full(ss.size, j_)); pair_s.append(ss.reshape(-1)); pair_j.append(jj.reshape(-1))
             logits_full = torch.zeros((len(envs), n_max, k_max, 2), dtype=torch.float32, device=self.device)
             if pair_e:
-                pe, ps_, pj = (torch.from_numpy(np.concatenate(x)).to(self.device) for x in (pair_e, pair_s, pair_j))
+                pe_h, ps_h, pj_h = (np.concatenate(x) for x in (pair_e, pair_s, pair_j))
+                pe, ps_, pj, pair_new, pair_slot = self._i32_many(pe_h, ps_h, pj_h, pe_h * n_max + ps_h, slots_h[pe_h])   # (int32 index tensors)
                 pair_inst = idx[pe, ps_, pj].contiguous()
-                pair_new = (pe * n_max + ps_).to(torch.int32).contiguous()
                 if trainer is not None:                                       # discriminator loss; the memory merges by ground truth (PRE-FF:1029-1047)
-                    logits_full[pe, ps_, pj] = trainer.merge(pools, slot[pe].contiguous(), pe, ps_, pj, pair_inst, len(envs))
+                    logits_full[pe, ps_, pj] = trainer.merge(pools, pair_slot, pe, ps_, pj, pair_inst, len(envs))
                 else:
-                    x = ops.merge_input(pools, new_fts, centroid, slot[pe].contiguous(), pair_inst, pair_new)
+                    x = ops.merge_input(pools, new_fts, centroid, pair_slot, pair_inst, pair_new)
                     logits_full[pe, ps_, pj] = self.dense.merge_logits(x)
             d2_h, idx_h, logits_h, cell_h = d2.cpu().numpy(), idx.cpu().numpy(), logits_full.cpu().numpy(), cell.cpu().numpy()  # sync #2
 
@@ -439,14 +454,13 @@ class Feature_Fields:
             if trainer is not None:
                 trainer.new_instances(pools, new_s, new_r, new_src)
             if new_r:                                                        # VLN-FF:643-648
-                s, r, src = self._i32(new_s), self._i32(new_r), self._i32(new_src)
+                s, r, src = self._i32_many(new_s, new_r, new_src)
                 ops.scatter_rows(pools.inst_pos, s, r, centroid, src)
                 ops.scatter_rows(pools.inst_fts, s, r, new_fts, src)
             dirty_cells = np.zeros((0, 3), np.int32)
             if m_lens:                                                       # VLN-FF:662-688
-                ts, tr = self._i32(np.concatenate(m_tok_slot)), self._i32(np.concatenate(m_tok_row))
-                goff = self._i32(np.concatenate([[0], np.cumsum(m_lens)]))
-                gs, gi = self._i32(m_slot), self._i32(m_inst)
+                ts, tr, goff, gs, gi = self._i32_many(np.concatenate(m_tok_slot), np.concatenate(m_tok_row), np.concatenate([[0], np.cumsum(m_lens)]),
+                                                      m_slot, m_inst)
                 _, mcell, mgeom = ops.group_stats7(pools, ts, tr, goff, len(m_lens), self.cell_len, pools.inst_pos, gs, gi)
                 mfts = ops.gather_fts(pools, ts, tr)
                 merged = self.dense.encode_patch_sets(mfts, mgeom, m_lens)
@@ -463,11 +477,10 @@ class Feature_Fields:
                     z_lens.append(len(mem)); z_mode.append(int(zmode[t])); z_slot.append(self.slots[e]); z_row.append(int(zrow[t]))
             self._grow_slots("zone", max(st.count(e, st.ZROWS) for e in envs))
             if z_lens:
-                ts = self._i32(np.concatenate(z_tok_slot) if sum(z_lens) else np.zeros(0, np.int32))
-                ti = self._i32(np.concatenate(z_tok_inst) if sum(z_lens) else np.zeros(0, np.int32))
-                goff = self._i32(np.concatenate([[0], np.cumsum(z_lens)]))
-                gs, gr = self._i32(z_slot), self._i32(z_row)
-                geom4 = ops.group_stats4(pools, ts, ti, goff, self._i32(z_mode), gs, gr, len(z_lens), self.cell_len)
+                ts, ti, goff, gs, gr, zm = self._i32_many(np.concatenate(z_tok_slot) if sum(z_lens) else np.zeros(0, np.int32),
+                                                          np.concatenate(z_tok_inst) if sum(z_lens) else np.zeros(0, np.int32),
+                                                          np.concatenate([[0], np.cumsum(z_lens)]), z_slot, z_row, z_mode)
+                geom4 = ops.group_stats4(pools, ts, ti, goff, zm, gs, gr, len(z_lens), self.cell_len)
                 ifts = ops.gather_rows(pools.inst_fts, ts, ti) if sum(z_lens) else torch.zeros((0, FTS), device=self.device)
                 zfts = self.dense.encode_zone_sets(ifts, geom4, z_lens)
                 ops.scatter_rows(pools.zone_fts, gs, gr, zfts)

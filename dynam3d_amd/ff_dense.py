@@ -85,9 +85,15 @@ class FFDense:
         idx[member] = np.arange(T)
         dev = self.device
         src = torch.cat([emb, cls], 0)
-        x = src.index_select(0, torch.from_numpy(idx).to(dev))
-        set_off = torch.from_numpy(poff.astype(np.int32)).to(dev)
-        cls_t = torch.from_numpy(cls_rows).to(dev)
+        # one upload for the three index arrays (int32: index_select takes it; every small copy is host time on the update's latency chain)
+        n_idx, n_off = T + G, G + 1
+        o_off, o_cls = (n_idx + 3) // 4 * 4, (n_idx + 3) // 4 * 4 + (n_off + 3) // 4 * 4
+        packed = np.zeros(o_cls + G, np.int32)
+        packed[:n_idx], packed[o_off:o_off + n_off], packed[o_cls:] = idx, poff, cls_rows
+        packed_d = torch.from_numpy(packed).to(dev, non_blocking=True)
+        x = src.index_select(0, packed_d[:n_idx])
+        set_off = packed_d[o_off:o_off + n_off]
+        cls_t = packed_d[o_cls:]
         max_len = int(lens.max()) + 1
         f = self._f32()
         for i in range(2):                                                # post-LN nn.TransformerEncoderLayer: 7 launches per layer

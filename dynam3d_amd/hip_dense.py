@@ -74,7 +74,7 @@ class HipDense:
 
     @staticmethod
     def _stream():
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _lib.current_stream_ptr()
 
     @staticmethod
     def gemm_ok(x, w):

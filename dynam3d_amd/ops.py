@@ -122,7 +122,7 @@ class HipOps:
     # -- helpers ------------------------------------------------------------------------------
     @staticmethod
     def _stream():
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _lib.current_stream_ptr()
 
     @staticmethod
     def _ck(rc):

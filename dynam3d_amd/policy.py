@@ -215,7 +215,16 @@ class Dynam3D_VLN:
         if cuda:
             main = torch.cuda.current_stream()
             ready = main.record_event()                                                       # depth / pools ready, CLIP not yet queued
-        _, grid = self.rgb_encoder.forward(pixels)                                            # (B*V,576,768) fp16, stays on device
+        # The llava tower is released behind CLIP block `LLAVA_AFTER_CLIP_BLOCK` (not behind the whole CLIP tower): it is the longer of the two
+        # things that follow CLIP (the 3D-token update's host-paced chain and the llava tower), so it gets a head start under CLIP's tail.
+        llava_go = None
+        if cuda and 0 <= self.LLAVA_AFTER_CLIP_BLOCK < self.rgb_encoder.cfg.layers - 1:
+            llava_go = torch.cuda.Event()
+            self.rgb_encoder.after_block = (self.LLAVA_AFTER_CLIP_BLOCK, lambda: llava_go.record(main))
+        try:
+            _, grid = self.rgb_encoder.forward(pixels)                                        # (B*V,576,768) fp16, stays on device
+        finally:
+            self.rgb_encoder.after_block = None
         # The frustum cull needs the depth and the stored rows, not the CLIP features: it runs -- with its host round trip for the
         # hit lists -- on a third stream UNDER the CLIP tower, which the host has only queued at this point.
         if delete_old_features:
@@ -236,7 +245,10 @@ class Dynam3D_VLN:
         side = None
         if cuda:
             side = self._side_stream()
-            side.wait_stream(main)
+            if llava_go is not None:
+                side.wait_event(llava_go)
+            else:
+                side.wait_stream(main)
             with torch.cuda.stream(side):
                 patch_feat = self.llava_vision.forward(pixels)
             pixels.record_stream(side)
@@ -273,6 +285,9 @@ class Dynam3D_VLN:
         """(ids in front of the visual prefix, ids behind it) = the reference's `inputs_embeds[:, :2]` / `[:, n_visual + 2:]` of the
         prompt tokenised with one "<image>" per visual token (VLN-POL:436-438, 456): `PromptTokenizer.split_prompt`."""
         return self.tokenizer.split_prompt(self.PROMPT_HEAD, n_visual, self._prompt_text(b, instructions))
+
+    # CLIP block (0-based) behind which the llava tower may start; -1 = behind the whole CLIP tower (D3D_LLAVA_AFTER_CLIP_BLOCK)
+    LLAVA_AFTER_CLIP_BLOCK = int(__import__("os").environ.get("D3D_LLAVA_AFTER_CLIP_BLOCK", "-1"))
 
     ASSEMBLE_KERNEL = True          # packed prompt rows by d3d_assemble_prompt (one pass); False: the PyTorch expressions below (the test's reference)
 

@@ -70,7 +70,7 @@ class FieldRenderer:
 
     @staticmethod
     def _stream():
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _lib.current_stream_ptr()
 
     @torch.no_grad()
     def _pinhole_tables(self, fx: float, fy: float):

@@ -73,7 +73,7 @@ def mlp_fused(lib, x, weights, modes, aux=None, save=None):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.current_stream_ptr()
 
 
 def _p(t):

@@ -158,9 +158,16 @@ class _VitTrunk:
         h = D.linear(h.view(B * L, W), blk["fc1_w"], blk["fc1_b"], act="quick_gelu")
         return D.linear(h, blk["fc2_w"], blk["fc2_b"], residual=x.view(B * L, W)).view(B, L, W)
 
+    # (layer index, callable) set by the policy: called once, right after that block has been QUEUED -- it records the event behind which the
+    # other vision tower starts (policy.build_inputs), so that the two towers overlap for the last blocks of this one
+    after_block = None
+
     def run_blocks(self, x: torch.Tensor, n_layers: int) -> torch.Tensor:
+        hook = self.after_block
         for i in range(n_layers):
             x = self.block(i, x)
+            if hook is not None and i == hook[0]:
+                hook[1]()
         return x
 
 

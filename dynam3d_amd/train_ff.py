@@ -38,7 +38,7 @@ def _p(t):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.current_stream_ptr()
 
 
 def gemm_nt_f32(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
