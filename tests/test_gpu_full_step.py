@@ -115,6 +115,28 @@ def test_packed_prompt_kernel_equals_torch_assembly(full_net):
         assert float(x_k[sum(lens_k):].abs().max()) == 0.0
 
 
+def test_whole_step_is_bitwise_repeatable(full_net):
+    """RGB-D -> logits, three warm steps at the benchmark's configuration, run twice from a reset memory on the same frames: identical
+    logits bit for bit.  Covers what the per-kernel tests cannot: stream hand-offs (frustum cull / llava tower on side streams), the
+    3D-token update's host round trips, split-precision GEMMs, LDS-DMA attention, split-K reductions -- any race, uninitialised read or
+    missing hazard wait between them shows up as a last-bit difference here (the inline-asm MFMA hazard of round 3 did)."""
+    from dynam3d_amd.synthetic import INSTRUCTION_64, SyntheticEpisodes
+    net, B = full_net, 8
+    instr = [INSTRUCTION_64] * B
+    runs = []
+    for rep in range(2):
+        net.feature_fields.reset(B)
+        ep = SyntheticEpisodes(B, seed=21)
+        outs = []
+        for step in range(3):
+            obs, pos, hd, segm = _frame(ep)
+            outs.append(net.forward_logits(obs, instr, pos, hd, patch_segm=segm).clone())
+        runs.append(outs)
+    for step, (a, b) in enumerate(zip(*runs)):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), (step, float((a - b).abs().max()))
+
+
 def test_config3_rollout_8_episodes_50_steps_full_model(full_net):
     """BASELINE configs[3] on one rank: 8 concurrent episodes, max_traj_len 50 (VLN/scripts/iter_train.yaml:41), the full model."""
     from dynam3d_amd.rollout import run_rollout
