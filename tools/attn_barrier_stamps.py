@@ -7,7 +7,7 @@ import numpy as np, torch
 from dynam3d_amd import _lib
 from dynam3d_amd.hip_dense import HipDense
 hd = HipDense()
-os.environ.setdefault("D3D_ATTN_V3", "0")          # the stamps live in the v2 kernel
+HipDense.ATTN_V3 = False                              # the stamps live in the v2 kernel
 lib = _lib.load()
 lib.d3d_fa_stamp_read.argtypes = [C.c_void_p, C.c_int32]
 buf = (C.c_ulonglong * 4)()
