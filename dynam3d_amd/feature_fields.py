@@ -28,6 +28,10 @@ import torch
 from .ops import pinhole_unproject_rows, pinhole_views, FTS, CameraTables, Pools, make_pose
 from ._ffstate import FFState
 from .ff_dense import FFDense
+from .modules import RefreshOnChange, install_param
+
+RENDER_PREFIXES = ("nerf_", "patch_to_nerf_", "aggregate_patch_to_nerf_")          # Pretrain-only renderer parameters (PRE-FF:221-254)
+IGNORED_PREFIXES = ("FastSAM", "freezed_", "clip_")                                 # sub-networks / frozen copies the memory update never reads
 
 K_MAX_CHOICES = (1, 2, 4, 8)
 
@@ -57,12 +61,20 @@ def _ray0_tan(fx_view: float, view_width: int, near: float, far: float, n_sample
     return math.fabs(math.tan(-math.atan(x / z)))
 
 
-class Feature_Fields:
+class Feature_Fields(RefreshOnChange):
+    """A `torch.nn.Module` like the reference's (VLN-FF:119): its parameters sit under the reference's own state-dict keys
+    (`weights.ff_param_spec`, float32), so `parameters()`, `state_dict()`, `load_state_dict(torch.load("dynam3d.pth"), strict=True)`
+    (VLN-POL:77-80), `to()`, `eval()` behave as the trainer expects; the kernels' view of them is `self.dense` (ff_dense.FFDense,
+    aliasing the parameter storage), rebuilt by `refresh()` when the parameters were replaced."""
+
     def __init__(self, batch_size: int = 1, device="cuda", state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  compat: str = "reference", max_steps: int = 64, max_views: int = 1, m_cap: int = 4096, z_cap: int = 2048,
-                 ops=None, segmenter=None, variant: str = "vln"):
+                 ops=None, segmenter=None, variant: str = "vln", seed: int = 0):
         """variant: "vln" = the VLN class's argument defaults (VLN-FF:22-46, 2 merge proposals); "pretrain" = the Pretrain
-        class's (PRE-FF:29-45: `num_proposal_instances` 4) -- the memory update itself is the same state machine."""
+        class's (PRE-FF:29-45: `num_proposal_instances` 4) -- the memory update itself is the same state machine.
+        `state_dict=None`: seeded synthetic parameters (the reference constructs with random initial weights and loads
+        `dynam3d.pth` afterwards, VLN-POL:77-80)."""
+        super().__init__()
         self.device = torch.device(device)
         self.args = _args_namespace()
         if variant not in ("vln", "pretrain"):
@@ -78,8 +90,16 @@ class Feature_Fields:
         self._m_cap, self._z_cap = m_cap, z_cap
         self.segmenter = segmenter              # callable(batch_image) -> (N,1,24,24) dense int labels (a6)
         self.dense: Optional[FFDense] = None
-        if state_dict is not None:
-            self.load_state_dict(state_dict)
+        self._renderer = None
+        self._sig = None
+        if state_dict is None:
+            from .weights import ff_param_spec, synth_state_dict
+            state_dict = synth_state_dict(ff_param_spec(int(self.args.fts_dim)), seed)
+        for k, v in state_dict.items():
+            if not k.startswith(IGNORED_PREFIXES):
+                install_param(self, k, v.detach().to(self.device, torch.float32).contiguous())
+        self._init_refresh_hooks()
+        self.refresh()
         self.state = FFState(ops.lib, compat, self.P, self.args.num_proposal_instances)
         self._cam: Optional[CameraTables] = None
         self.pools: Optional[Pools] = None
@@ -94,14 +114,33 @@ class Feature_Fields:
     def cell_len(self):
         return (float(self.args.zone_x_length), float(self.args.zone_y_length), float(self.args.zone_z_length))
 
-    def load_state_dict(self, sd, strict: bool = True):
-        """Accepts the reference's keys (convert_ckpt.py).  Pretrain-only renderer keys (`nerf_*`,
-        `patch_to_nerf_*`, `aggregate_patch_to_nerf_*`) enable `render_view_3d_patch` when present."""
-        self._render_sd = {k: v for k, v in sd.items() if k.startswith(("nerf_", "patch_to_nerf_", "aggregate_patch_to_nerf_"))}
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """`nn.Module.load_state_dict` over the reference's keys (`dynam3d.pth` after convert_ckpt.py).  Keys of sub-networks the
+        memory update never reads (`FastSAM.*`, `freezed_*`, `clip_*`) are dropped; Pretrain-only renderer keys (`nerf_*`,
+        `patch_to_nerf_*`, `aggregate_patch_to_nerf_*`) are registered on first sight and enable `render_view_3d_patch`."""
+        sd = {k: v for k, v in state_dict.items() if not k.startswith(IGNORED_PREFIXES)}
+        own = set(dict(self.named_parameters()))
+        for k, v in sd.items():
+            if k.startswith(RENDER_PREFIXES) and k not in own:
+                install_param(self, k, v.detach().to(self.device, torch.float32).contiguous())
+        return super().load_state_dict(sd, strict=strict, assign=assign)
+
+    def refresh(self):
+        """Re-derive the kernels' view of the parameters (called by the nn.Module hooks, modules.RefreshOnChange; a no-op while
+        the parameters' storages are the ones the current view aliases)."""
+        params = dict(self.named_parameters())
+        sig = tuple((k, p.data_ptr(), p._version, p.dtype, p.device) for k, p in params.items())
+        if sig == self._sig:
+            return
+        self._sig = sig
+        if params:
+            dev = next(iter(params.values())).device
+            if dev != self.device:
+                self.device = dev
+        flat = {k: p.detach() for k, p in params.items()}
+        self._render_sd = {k: v for k, v in flat.items() if k.startswith(RENDER_PREFIXES)}
         self._renderer = None
-        sd = {k: v for k, v in sd.items() if not k.startswith("FastSAM") and k not in self._render_sd}
-        self.dense = FFDense(sd, self.device, n_head=int(self.args.fts_dim) // 64)
-        return self
+        self.dense = FFDense({k: v for k, v in flat.items() if k not in self._render_sd}, self.device, n_head=int(self.args.fts_dim) // 64)
 
     # ---- a20-a23: PRE-FF:494-625 ----------------------------------------------------------------------
     @torch.no_grad()
@@ -123,12 +162,6 @@ class Feature_Fields:
         n_rows = [st.count(e, st.ROWS) for e in range(self.batch_size)]
         out = self._renderer.render(self.pools, self.slots, n_rows, batch_position, batch_heading, self.ops, debug=debug, **pin)
         return (out[0], out[1], []) + tuple(out[2:])
-
-    def eval(self):
-        return self
-
-    def parameters(self):
-        return list(self.dense.w.values()) if self.dense else []
 
     # ---- lifecycle (VLN-FF:186-240) ------------------------------------------------------------
     def reset(self, batch_size: int = 1):

@@ -19,7 +19,8 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from .feature_fields import Feature_Fields
-from .towers import ClipVisionTower, VitConfig, preprocess_rgb
+from .modules import RefreshOnChange
+from .towers import ClipEncoder, VitConfig, preprocess_rgb
 from .weights import ff_param_spec
 
 NUM_IMGS = 12
@@ -36,9 +37,13 @@ def clockwise_sources(observations: Dict[str, torch.Tensor], view_ids: Sequence[
     return [slot_to_key[int(v)] for v in view_ids]
 
 
-class Net_3DFF:
+class Net_3DFF(RefreshOnChange):
+    """`torch.nn.Module` like the reference's `Net_3DFF` (PRE-POL:66-115): `feature_fields.*` and `rgb_encoder.model.visual.*`
+    parameters under the reference's keys (modules.py)."""
+
     def __init__(self, vit: VitConfig, weights: Dict[str, torch.Tensor], device="cuda", batch_size: int = 1, ops=None,
                  clip_dtype=torch.float16, segmenter=None, max_steps: int = 16, depth_scale=(0.0, 10.0)):
+        super().__init__()
         self.device = torch.device(device)
         if self.device.type == "cuda":
             from . import dense_ops as D
@@ -47,13 +52,15 @@ class Net_3DFF:
         self.feature_fields = Feature_Fields(batch_size, device, ff_sd, ops=ops, segmenter=segmenter, max_steps=max_steps,
                                              max_views=len(VIEW_IDS), variant="pretrain")
         self.ops = self.feature_fields.ops
-        self.rgb_encoder = ClipVisionTower(weights, vit, clip_dtype, device)
+        self.rgb_encoder = ClipEncoder(weights, vit, clip_dtype, device)
+        self._init_refresh_hooks()
         self.depth_scale = depth_scale                                  # PRE-POL:121-122 (R2R: 0 .. 10 m)
         self.positions: List = [0 for _ in range(batch_size)]          # set by the caller before forward (PRE-POL:104-105)
         self.headings: List = [0 for _ in range(batch_size)]
 
-    def __call__(self, *a, **k):
-        return self.forward(*a, **k)
+    def refresh(self):
+        self.feature_fields.refresh()
+        self.rgb_encoder.refresh()
 
     def preprocess_depth(self, depth):
         """PRE-POL:118-133; (N,H,W,1) in [0,1] -> metres, zero pixels <- column max."""
@@ -77,7 +84,7 @@ class Net_3DFF:
         rgb = torch.stack([observations[k.replace("depth", "rgb")] for k in keys], 1).to(self.device)           # (B,V,h,w,3)
         rgb = rgb.view(B * V, *rgb.shape[2:])
         depth = depth.view(B * V, *depth.shape[2:])
-        cls, grid = self.rgb_encoder.forward(preprocess_rgb(rgb))                                                 # PRE-POL:176
+        cls, grid = self.rgb_encoder.tower.forward(preprocess_rgb(rgb))                                                 # PRE-POL:176
         a = ff.args
         depth24 = self.ops.resize_nearest_preprocess(depth[..., 0], a.input_height, a.input_width, *self.depth_scale).view(B, V, -1)
         origin_depth = self.ops.preprocess_depth(depth[..., 0], *self.depth_scale).view(B, V, depth.shape[1], depth.shape[2])

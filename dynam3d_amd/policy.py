@@ -29,10 +29,13 @@ import torch
 from . import dense_ops as D
 from .adapters import PromptTokenizer
 from .feature_fields import Feature_Fields
+from .modules import DepthEncoderSlot, RefreshOnChange, make_prefix_mlp
 from .profiling import TIMER
-from .towers import (ClipVisionTower, LlavaVisionTower, Phi3Config, Phi3Decoder, VitConfig, clip_param_spec,
-                     llava_vision_param_spec, phi3_param_spec, preprocess_rgb)
+from .towers import (ClipEncoder, LlavaModel, Phi3Config, VitConfig, clip_param_spec, llava_vision_param_spec, phi3_param_spec,
+                     preprocess_rgb)
 from .weights import ff_param_spec, synth_state_dict
+
+PREFIX_MLPS = ("patch_position_embedding", "instance_position_embedding", "zone_position_embedding", "instance_projector", "zone_projector")
 
 
 def prefix_param_spec(width: int = 768, hidden: int = None):
@@ -116,23 +119,77 @@ def synth_policy_weights(cfg: PolicyConfig, seed: int = 0, device: str = "cpu") 
     return synth_state_dict(spec, seed, device=device, dtype_for=dtype_for)
 
 
-class Dynam3D_VLN:
+class Dynam3D_VLN(RefreshOnChange):
+    """A `torch.nn.Module` with the reference net's module tree (VLN-POL:66-155), so that the UNCHANGED trainer can hold it as
+    `ILPolicy.net` (models/policy.py:12-19): `feature_fields.*`, the five prefix MLPs as `nn.Sequential`s, `llava.language_model.* /
+    .vision_tower.* / .multi_modal_projector.*`, `rgb_encoder.model.visual.*`, `depth_encoder` (a slot, modules.DepthEncoderSlot) --
+    `parameters()`, `to()`, `train()/eval()`, `state_dict()` / `load_state_dict(strict=False)` work as VLN-TR:183-219, 305-311, 374 use
+    them; `requires_grad` flags follow VLN-POL:150-155.  The kernels read their own layouts of these tensors (modules.py); `refresh()`
+    re-derives them after the parameters were replaced or overwritten and is called by the nn.Module hooks.  Call it yourself after
+    writing to `param.data` directly (an optimizer step)."""
+
     def __init__(self, cfg: PolicyConfig = PolicyConfig(), weights: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0,
-                 device="cuda", batch_size: int = 1, ops=None, tokenizer=None, segmenter=None, max_steps: int = 64):
+                 device="cuda", batch_size: int = 1, ops=None, tokenizer=None, segmenter=None, max_steps: int = 64,
+                 depth_encoder: Optional[torch.nn.Module] = None):
+        super().__init__()
         self.cfg, self.device = cfg, torch.device(device)
         if self.device.type == "cuda" and cfg.hip_dense:
             D.enable_hip_kernels(["all"])             # before the towers are built: they lay their weights out for these kernels
         sd = weights if weights is not None else synth_policy_weights(cfg, seed)
         ff_sd = {k: sd[k] for k, _ in ff_param_spec(768)}
         self.feature_fields = Feature_Fields(batch_size, device, ff_sd, compat=cfg.compat, ops=ops, segmenter=segmenter, max_steps=max_steps)
+        self.feature_fields.requires_grad_(False)                                             # VLN-POL:150-151 ("Avoid DDP bug")
         self.ops = self.feature_fields.ops
-        self.rgb_encoder = ClipVisionTower(sd, cfg.vit, cfg.clip_dtype, device)
-        self.llava_vision = LlavaVisionTower(sd, cfg.vit, cfg.llava_dtype, device)
-        self.llm = Phi3Decoder(sd, cfg.llm, cfg.llava_dtype, device)
-        self.mlp_w = {k: sd[k].to(self.device, torch.float32).contiguous() for k, _ in prefix_param_spec(768, cfg.llm.hidden)}
+        width, hidden = 768, cfg.llm.hidden
+        for name, (din, dh, dout) in zip(PREFIX_MLPS, ((6, hidden, hidden), (3, width, width), (3, width, width),
+                                                       (2 * width, hidden, hidden), (2 * width, hidden, hidden))):        # VLN-POL:83-111
+            setattr(self, name, make_prefix_mlp(din, dh, dout, self.device, sd, name + "."))
+        self.llava = LlavaModel(sd, cfg.vit, cfg.llm, cfg.llava_dtype, device)
+        self.depth_encoder = depth_encoder if depth_encoder is not None else DepthEncoderSlot()
+        self.space_pool_depth = torch.nn.Sequential(torch.nn.AdaptiveAvgPool2d((1, 1)), torch.nn.Flatten(start_dim=2))   # VLN-POL:144
+        self.rgb_encoder = ClipEncoder(sd, cfg.vit, cfg.clip_dtype, device)
+        self.pano_img_idxes = np.arange(0, 12, dtype=np.int64)                                # VLN-POL:147-149 (read by get_candidate_waypoints)
+        ang = torch.from_numpy((1 - self.pano_img_idxes / 12) * 2 * math.pi)
+        self.pano_angle_fts = torch.stack([torch.sin(ang), torch.cos(ang), torch.sin(torch.zeros_like(ang)), torch.cos(torch.zeros_like(ang))], 1).float()
         self.tokenizer = tokenizer or SyntheticTokenizer(cfg.llm.vocab)
         self.last_lengths = None
-        self._lowp_w = {}
+        self._mlp_sig = None
+        self._init_refresh_hooks()
+        self.refresh()
+
+    # the compute objects over `self.llava`'s parameters
+    @property
+    def llava_vision(self):
+        return self.llava.vision
+
+    @property
+    def llm(self):
+        return self.llava.lm
+
+    def refresh(self):
+        """Re-derive every kernel-side weight layout from the current parameters (no-op for parts whose storages are unchanged)."""
+        self.feature_fields.refresh()
+        self.rgb_encoder.refresh()
+        self.llava.refresh()
+        mlp_params = [p for n in PREFIX_MLPS for p in getattr(self, n).parameters()]
+        sig = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in mlp_params)
+        if sig != self._mlp_sig:
+            self._mlp_sig = sig
+            self.mlp_w = {f"{n}.{k}": p.detach().to(self.device, torch.float32).contiguous() for n in PREFIX_MLPS for k, p in getattr(self, n).named_parameters()}
+            self._lowp_w = {}
+
+    # ---- habitat `Net` properties the trainer / registry reads (VLN-POL:158-169) --------------------------------------
+    @property
+    def output_size(self):
+        return 1
+
+    @property
+    def is_blind(self):
+        return False
+
+    @property
+    def num_recurrent_layers(self):
+        return 1
 
     def _cull_stream(self):
         if getattr(self, "_cull", None) is None:
@@ -145,9 +202,6 @@ class Dynam3D_VLN:
         return self._side
 
     # ---- reference surface -----------------------------------------------------------------------------
-    def __call__(self, *a, **k):
-        return self.forward(*a, **k)
-
     def preprocess_depth(self, depth, depth_scale=(0.0, 10.0)):
         """VLN-POL:171-186; depth (B,H,W,1) -> same shape, metres."""
         d = depth.to(self.device)
@@ -218,13 +272,14 @@ class Dynam3D_VLN:
         # The llava tower is released behind CLIP block `LLAVA_AFTER_CLIP_BLOCK` (not behind the whole CLIP tower): it is the longer of the two
         # things that follow CLIP (the 3D-token update's host-paced chain and the llava tower), so it gets a head start under CLIP's tail.
         llava_go = None
-        if cuda and 0 <= self.LLAVA_AFTER_CLIP_BLOCK < self.rgb_encoder.cfg.layers - 1:
+        clip = self.rgb_encoder.tower
+        if cuda and 0 <= self.LLAVA_AFTER_CLIP_BLOCK < clip.cfg.layers - 1:
             llava_go = torch.cuda.Event()
-            self.rgb_encoder.after_block = (self.LLAVA_AFTER_CLIP_BLOCK, lambda: llava_go.record(main))
+            clip.after_block = (self.LLAVA_AFTER_CLIP_BLOCK, lambda: llava_go.record(main))
         try:
-            _, grid = self.rgb_encoder.forward(pixels)                                        # (B*V,576,768) fp16, stays on device
+            _, grid = clip.forward(pixels)                                                    # (B*V,576,768) fp16, stays on device
         finally:
-            self.rgb_encoder.after_block = None
+            clip.after_block = None
         # The frustum cull needs the depth and the stored rows, not the CLIP features: it runs -- with its host round trip for the
         # hit lists -- on a third stream UNDER the CLIP tower, which the host has only queued at this point.
         if delete_old_features:
@@ -424,6 +479,47 @@ class Dynam3D_VLN:
             self.feature_fields.history_actions[b].pop(0)                                       # VLN-POL:466-468
             self.feature_fields.history_actions[b].append(t + "\n")
         return texts
+
+    # ---- teacher text (VLN-POL:294-327; called by the trainer in 'train' mode, VLN-TR:664, 676) ----------------------------
+    def get_gt_text(self, target_angles, target_distances, stop_actions):
+        """(angle rad CCW, distance m, stop flag) per environment -> the action sentence the LM is trained to emit, and the side
+        effect the reference has: a turn of >= 4 steps is capped at 4 and the REMAINING turn + the move are parked in
+        `feature_fields.keep_target_waypoint[b]` for the next step.  A sentence whose first 17 characters repeat the history the way the
+        reference checks it (entries -2 and -4 against this sentence, entry -3 against the LAST environment's sentence -- the
+        reference's own indexing, reproduced) becomes "error.<|end|>".  Pinned by tests/golden/g20_gt_text.json."""
+        ff = self.feature_fields
+        step_deg, step_m, cap = 15, 0.25, 4
+        degs = [round(np.degrees(a)) for a in target_angles]
+        texts = ["" for _ in degs]
+        for b, (deg, dist) in enumerate(zip(degs, target_distances)):
+            if stop_actions[b] == True:      # noqa: E712  (the reference compares with ==)
+                texts[b] = "stop.<|end|>"
+            else:
+                turns = round(deg / step_deg)
+                move = " move " + str(round(dist / step_m)) + " steps.<|end|>"
+                left = "turn left " + str(turns) + " steps," + move
+                right = "turn right " + str(round((360 - deg) / step_deg)) + " steps," + move
+                if cap <= turns < 360 // step_deg:
+                    go_left = turns < 180 // step_deg
+                    texts[b] = left if go_left else right
+                    rest = deg - cap * step_deg if go_left else deg + cap * step_deg
+                    ff.keep_target_waypoint[b] = [(np.radians(rest) + math.pi * 2) % (math.pi * 2), dist]
+                else:
+                    texts[b] = left if turns < cap else right
+                    ff.keep_target_waypoint[b] = None
+            n = len("turn left 4 steps")
+            h = ff.history_actions[b]
+            if h[-2][:n] == texts[b][:n] and h[-4][:n] == texts[b][:n] and h[-3][:n] == texts[-1][:n]:
+                texts[b] = "error.<|end|>"
+        return texts
+
+    def get_candidate_waypoints(self, waypoint_predictor=None, observations=None):
+        """VLN-POL:188-292: the waypoint predictor over the DDPPO depth encoder's 12-view embedding -- outside the hot path
+        (SURVEY.md section 2).  The attributes that function reads exist on this module (`depth_encoder`, `space_pool_depth`,
+        `pano_angle_fts`, `pano_img_idxes`), so on a machine with Habitat the reference's own function can be bound unchanged:
+        `net.get_candidate_waypoints = types.MethodType(RefNet.get_candidate_waypoints, net)` with
+        `Dynam3D_VLN(depth_encoder=VlnResnetDepthEncoder(...))`."""
+        raise NotImplementedError("get_candidate_waypoints is outside the hot path (SURVEY.md section 2); bind the reference's function, see the docstring")
 
     # ---- a18 (VLN-POL:472-506) ----------------------------------------------------------------------------------
     @staticmethod

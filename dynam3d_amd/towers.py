@@ -20,8 +20,10 @@ from dataclasses import dataclass
 from typing import Dict, Optional
 
 import torch
+from torch import nn
 
 from . import dense_ops as D
+from .modules import ParamTree, install_param
 from .profiling import TIMER
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
@@ -174,7 +176,14 @@ class _VitTrunk:
 class ClipVisionTower(_VitTrunk):
     def __init__(self, sd: Dict[str, torch.Tensor], cfg: VitConfig = VitConfig(), dtype=torch.float16, device="cuda"):
         super().__init__(cfg, dtype, device)
+        self.load(sd)
+
+    def load(self, sd: Dict[str, torch.Tensor]):
+        """(Re-)derive the kernel layouts from the `visual.*` tensors; tensors that already have the tower's dtype / device / a contiguous
+        [out, in] layout are ALIASED, not copied (modules.py)."""
+        cfg = self.cfg
         t, f = self._t, self._f
+        self.blocks = []
         self.patch_w = self._patch_weight(sd["visual.conv1.weight"])
         self.cls, self.pos = t(sd["visual.class_embedding"]), t(sd["visual.positional_embedding"])
         self.ln_pre = (f(sd["visual.ln_pre.weight"]), f(sd["visual.ln_pre.bias"]))
@@ -204,7 +213,13 @@ class LlavaVisionTower(_VitTrunk):
     def __init__(self, sd: Dict[str, torch.Tensor], cfg: VitConfig = VitConfig(), dtype=torch.bfloat16, device="cuda",
                  feature_layer: int = -2):
         super().__init__(cfg, dtype, device)
+        self.feature_layer = feature_layer
+        self.load(sd)
+
+    def load(self, sd: Dict[str, torch.Tensor]):
+        cfg, feature_layer = self.cfg, self.feature_layer
         t, f = self._t, self._fq                         # HF `torch_dtype=bfloat16` casts the LayerNorm parameters as well
+        self.blocks = []
         v = "vision_tower.vision_model"
         self.patch_w = self._patch_weight(sd[v + ".embeddings.patch_embedding.weight"])
         self.cls, self.pos = t(sd[v + ".embeddings.class_embedding"]), t(sd[v + ".embeddings.position_embedding.weight"])
@@ -240,6 +255,13 @@ class LlavaVisionTower(_VitTrunk):
 class Phi3Decoder:
     def __init__(self, sd: Dict[str, torch.Tensor], cfg: Phi3Config = Phi3Config(), dtype=torch.bfloat16, device="cuda"):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self._rope_cache = {}
+        self.load(sd)
+
+    def load(self, sd: Dict[str, torch.Tensor]):
+        """(Re-)derive the kernel layouts from the `language_model.*` tensors (aliasing where the layout is the reference's)."""
+        cfg, dtype = self.cfg, self.dtype
+        self._w_arrays = None                                                            # decode runner's weight pointer tables
         t = lambda x: x.detach().to(self.device, dtype).contiguous()
         f = lambda x: x.detach().to(self.device, dtype).to(torch.float32).contiguous()   # RMSNorm gains: values of the LM's dtype (HF casts them)
         m = "language_model.model"
@@ -258,7 +280,6 @@ class Phi3Decoder:
                                     n1=f(sd[p + ".input_layernorm.weight"]), n2=f(sd[p + ".post_attention_layernorm.weight"])))
         self.norm_w = f(sd[m + ".norm.weight"])
         self.lm_head_w = t(sd["language_model.lm_head.weight"])
-        self._rope_cache = {}
 
     PRUNE_LAST_LAYER = True            # prefill_logits_packed: the last layer's o_proj / MLP on the B last rows only
     MAX_DECODE_ROWS = 16          # k_gemm_skinny: M <= 16
@@ -537,3 +558,103 @@ def preprocess_rgb(rgb_u8: torch.Tensor, size: int = 336) -> torch.Tensor:
     """rgb (B,h,w,3) uint8 -> (B,3,336,336) float32 normalised: CHW, bicubic resize in float with the result
     rounded back to uint8 (torchvision's tensor path), /255, CLIP mean/std."""
     return D.resize_normalize(rgb_u8, size, CLIP_MEAN, CLIP_STD)
+
+
+# ---------------------------------------------------------------------------------------------------
+# nn.Module holders of the towers' parameters (SURVEY.md 8 b1; see modules.py for the two-copies design)
+# ---------------------------------------------------------------------------------------------------
+def _is_ln(name: str) -> bool:
+    return any(p.startswith("ln_") for p in name.split("."))
+
+
+def clip_storage_dtype(name: str, clip_dtype):
+    """What OpenAI CLIP's `convert_weights` (clip/model.py:373-395) leaves a `visual.*` tensor in: conv / linear / attention weights and
+    `proj` in fp16, LayerNorm parameters and the class / positional embeddings in float32 (cast at use, clip/model.py:225-226)."""
+    if _is_ln(name) or name in ("visual.class_embedding", "visual.positional_embedding"):
+        return torch.float32
+    return clip_dtype
+
+
+class ClipEncoder(nn.Module):
+    """`net.rgb_encoder` (encoders/resnet_encoders.py:245-284 `CLIPEncoder`): an nn.Module whose parameters are the image tower's under
+    the reference's keys `model.visual.*` (`self.model` = the CLIP model there), frozen like the reference's (:262-264).  The kernels run
+    in `self.tower` (`ClipVisionTower`); attributes / methods not found here (`cfg`, `blocks`, `block`, `embed`, ...) resolve there."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: VitConfig = VitConfig(), dtype=torch.float16, device="cuda"):
+        super().__init__()
+        dev = torch.device(device)
+        names = [n for n, _ in clip_param_spec(cfg)]
+        self.model = ParamTree({n: sd[n].detach().to(dev, clip_storage_dtype(n, dtype)).contiguous() for n in names})
+        self.tower = ClipVisionTower(self.flat(), cfg, dtype, dev)
+        self._sig = self._signature()
+
+    def flat(self) -> Dict[str, torch.Tensor]:
+        return self.model.flat()
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in self.model.parameters())
+
+    def refresh(self):
+        sig = self._signature()
+        if sig != self._sig:
+            self._sig = sig
+            self.tower.device = next(self.model.parameters()).device
+            self.tower.load(self.flat())
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            tower = self.__dict__.get("tower")
+            if tower is None or name.startswith("__"):
+                raise
+            return getattr(tower, name)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """`CLIPEncoder.forward(observations)` -> (view_fts (B,768), grid_fts (B,576,768)) (resnet_encoders.py:273-284); also accepts the
+        already pre-processed (B,3,336,336) float32 pixels the policy shares between its two vision towers."""
+        if isinstance(x, dict):
+            x = preprocess_rgb(x["rgb"].to(self.tower.device))
+        return self.tower.forward(x)
+
+
+class LlavaModel(nn.Module):
+    """`net.llava` (VLN-POL:119-131 `LlavaForConditionalGeneration`, transformers 4.46 layout): parameters under `language_model.*`,
+    `vision_tower.*`, `multi_modal_projector.*`, all in the model's dtype (`torch_dtype=torch.bfloat16` casts the norm gains too).
+    `vision` (`LlavaVisionTower`) and `lm` (`Phi3Decoder`) are the compute objects over them.  Trainable flags as the reference sets
+    them: vision tower and projector frozen (VLN-POL:152-155), the language model trainable."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], vit: VitConfig, llm: Phi3Config, dtype=torch.bfloat16, device="cuda"):
+        super().__init__()
+        dev = torch.device(device)
+        st = lambda n: sd[n].detach().to(dev, dtype).contiguous()
+        for n, _ in phi3_param_spec(llm):
+            self._add(n, st(n), True)
+        for n, _ in llava_vision_param_spec(vit):
+            self._add(n, st(n), False)
+        flat = self.flat()
+        self.vision = LlavaVisionTower(flat, vit, dtype, dev)
+        self.lm = Phi3Decoder(flat, llm, dtype, dev)
+        self._sig = self._signature()
+
+    def _add(self, dotted, tensor, requires_grad):
+        install_param(self, dotted, tensor, requires_grad)
+
+    def flat(self) -> Dict[str, torch.Tensor]:
+        return {k: p.detach() for k, p in self.named_parameters()}
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in self.parameters())
+
+    def refresh(self):
+        sig = self._signature()
+        if sig != self._sig:
+            self._sig = sig
+            flat = self.flat()
+            self.vision.device = self.lm.device = next(self.parameters()).device
+            self.vision.load(flat)
+            self.lm.load(flat)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("LlavaModel holds the parameters; Dynam3D_VLN drives `vision` / `lm` (packed prefill, KV-cache decode)")

@@ -306,9 +306,52 @@ def g7_text_to_action():
     print("g7 ok", rows)
 
 
+def g20_gt_text():
+    """Executes the reference's own `get_gt_text` (VLN-POL:294-327) -- located with `ast` and compiled in place, like g7 -- on seeded
+    (angle, distance, stop) batches with histories that exercise the capped-turn carry-over (`keep_target_waypoint`) and the
+    repeated-history "error" rule.  Data only: inputs, returned sentences, the carried waypoints."""
+    import ast
+    import json
+    from types import SimpleNamespace
+    path = os.path.join(rh.REF_ROOT, "Dynam3D_VLN/vlnce_baselines/models/Policy_Dynam3D_VLN.py")
+    tree = ast.parse(open(path).read())
+    fn = [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "get_gt_text"][0]
+    ns = {"math": math, "np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    f = ns["get_gt_text"]
+    rng = np.random.default_rng(200)
+    hist_pool = ["none\n", "turn left 4 steps, move 3 steps.\n", "turn right 2 steps, move 1 steps.\n", "turn left 1 steps, move 2 steps.\n",
+                 "turn right 4 steps, move 0 steps.\n", "stop.\n", "turn left 0 steps, move 5 steps.\n"]
+    cases = []
+    for c in range(60):
+        B = int(rng.integers(1, 5))
+        if c < 30:
+            angles = [float(rng.uniform(0, 2 * math.pi)) for _ in range(B)]
+        else:                                   # exact multiples / half steps of 15 degrees: the banker's-rounding corners
+            angles = [float(np.radians(rng.choice([0, 7.5, 15, 22.5, 52.5, 60, 67.5, 172.5, 180, 187.5, 300, 352.5, 359.6]))) for _ in range(B)]
+        dists = [float(rng.choice([0.25, 0.5, 0.75, 1.0, 1.1, 2.25, 2.9, 0.125, 0.375])) for _ in range(B)]
+        stops = [bool(rng.random() < 0.15) for _ in range(B)]
+        if c % 3 == 0:                          # histories that repeat one sentence -> the "error" rule can fire
+            rep = str(rng.choice(hist_pool[1:5]))
+            hist = [[rep, rep, rep, rep] for _ in range(B)]
+            if c % 2 == 0:                      # the angle whose sentence starts like the repeated history entry (only the LAST row can fire)
+                angles = [float(np.radians({1: 60.0, 2: 330.0, 3: 15.0, 4: 300.0}[hist_pool.index(rep)]))] * B
+                stops = [False] * B
+        else:
+            hist = [[str(rng.choice(hist_pool)) for _ in range(4)] for _ in range(B)]
+        me = SimpleNamespace(feature_fields=SimpleNamespace(keep_target_waypoint=[None] * B, history_actions=[list(h) for h in hist]))
+        out = f(me, list(angles), list(dists), list(stops))
+        keep = [None if k is None else [float(k[0]), float(k[1])] for k in me.feature_fields.keep_target_waypoint]
+        cases.append(dict(angles=angles, distances=dists, stops=stops, history=hist, text=out, keep=keep))
+    with open(os.path.join(OUT, "g20_gt_text.json"), "w") as fo:
+        json.dump(cases, fo, indent=0)
+    print("g20 ok", sum(t == "error.<|end|>" for c in cases for t in c["text"]), "error sentences,",
+          sum(k is not None for c in cases for k in c["keep"]), "carried waypoints")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7"]
     torch.set_num_threads(8)
-    fns = {"g1": g1_unproject, "g2": g2_frustum, "g2b": g2b_frustum_pinhole, "g3": g3_knn, "g4": g4_trajectories, "g7": g7_text_to_action, "g10": g10_patch_segm}
+    fns = {"g1": g1_unproject, "g2": g2_frustum, "g2b": g2b_frustum_pinhole, "g3": g3_knn, "g4": g4_trajectories, "g7": g7_text_to_action, "g10": g10_patch_segm, "g20": g20_gt_text}
     for w in which:
         fns[w]()
