@@ -147,6 +147,54 @@ def cpu_baseline(cfg, seed, B, warm_steps, gpu_lengths=None):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_guard(gpus: int):
+    """`--gpus N` must mean N ranks on N distinct GPUs, or no number at all.
+      * N > 1 without a launcher (WORLD_SIZE unset): re-launch this very command under `torch.distributed.run` with N ranks -- if the
+        box has N GPUs; otherwise exit non-zero (a plain `python bench.py --gpus 8` on one GPU used to print 8x one GPU's rate);
+      * under a launcher whose WORLD_SIZE differs from --gpus: exit non-zero.
+    Runs before anything is allocated."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != gpus:
+            sys.exit(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={world_env} ranks; refusing to report a number for a job that is not the one named")
+        return
+    if gpus == 1:
+        return
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get("D3D_SHARE_DEVICE0") == "1":
+        n_dev = max(n_dev, gpus if n_dev >= 1 else 0)          # test hook: several ranks on cuda:0 (see dynam3d_amd/dist.py)
+    if n_dev < gpus:
+        sys.exit(f"bench.py: --gpus {gpus} needs {gpus} GPUs, this machine shows {n_dev}; refusing to report a {gpus}-GPU number "
+                 f"(launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node {gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {gpus} ...)")
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher -> %s" % (gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd))
+
+
+def device_identity(index: int) -> str:
+    """Something that tells two GPUs of one node apart: the device UUID where torch exposes it, else PCI bus id, else the index."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        for attr in ("uuid", "pci_bus_id"):
+            v = getattr(p, attr, None)
+            if v not in (None, ""):
+                return f"{attr}:{v}"
+    except Exception:       # noqa: BLE001
+        pass
+    return f"index:{index}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +207,7 @@ def main():
                     help="comma list of dense primitives on hand-written HIP kernels (linear,layer_norm,rms_norm,rope,swiglu,resize_normalize), 'all' or 'none'")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
+    launch_guard(a.gpus)
 
     from dynam3d_amd import dense_ops as D
     from dynam3d_amd import dist as DD
@@ -167,7 +216,7 @@ def main():
     from dynam3d_amd.synthetic import INSTRUCTION_64, SyntheticEpisodes
 
     rank, local, world = DD.init_from_env()
-    assert world == a.gpus or world == 1, (world, a.gpus)
+    assert world == a.gpus, (world, a.gpus)                      # launch_guard() made sure of it
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     # --hip-dense alone decides the dense backend: "all" (default) = every primitive on a hand-written kernel AND strict mode (a
@@ -207,9 +256,17 @@ def main():
         lengths_seen.append(list(net.last_lengths))
     torch.cuda.synchronize()
     DD.barrier()
-    dt = DD.max_over_ranks(time.perf_counter() - t0, device=dev)
+    dt_own = time.perf_counter() - t0
+    dt = DD.max_over_ranks(dt_own, device=dev)
     TIMER.enabled = False
     assert torch.isfinite(lo).all()
+    # who actually worked: every rank reports its device and its own time (one all_gather_object); N ranks must be N distinct GPUs
+    shared_hook = os.environ.get("D3D_SHARE_DEVICE0") == "1"
+    rank_info = DD.gather_objects(dict(rank=rank, local_rank=local, device=device_identity(local), ms_per_step=round(dt_own / a.steps * 1e3, 3),
+                                       env_steps=B * a.steps, finite=bool(torch.isfinite(lo).all())))
+    devices_seen = len({r["device"] for r in rank_info})
+    if rank == 0 and not shared_hook and devices_seen != world:
+        sys.exit(f"bench.py: {world} ranks ran on {devices_seen} distinct GPU(s) {sorted({r['device'] for r in rank_info})}; not a {world}-GPU measurement")
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -249,8 +306,9 @@ def main():
             except (KeyError, ValueError, OSError) as e:            # a profile file that lacks the fields is reported, it does not stop the benchmark
                 traffic, traffic_note = None, "profiles/%s unusable (%s: %s)" % (os.path.basename(pj), type(e).__name__, e)
         out = {
-            "metric": "nav steps/sec (RGB-D obs->action logits) at batch=8", "value": round(B * a.steps * a.gpus / dt, 3), "unit": "env-steps/s",
-            "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "metric": "nav steps/sec (RGB-D obs->action logits) at batch=8", "value": round(sum(r["env_steps"] for r in rank_info) / dt, 3), "unit": "env-steps/s",
+            "n_gpus": world, "ranks_seen": len(rank_info), "devices_seen": devices_seen,
+            "per_rank": [dict(rank=r["rank"], device=r["device"], ms_per_step=r["ms_per_step"]) for r in sorted(rank_info, key=lambda r: r["rank"])], "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[2]: full Dynam3D-VLN step (3D tokens + llava-phi-3-mini prefill -> action logits), batch=8 synthetic 224x224 RGB-D, 1 MI355X per rank",
                        "batch_per_gpu": B, "operating_point": (f"warm: the timed steps are memory steps {a.warm_steps + a.warmup}..{total - 1} of the synthetic episodes "
@@ -260,7 +318,7 @@ def main():
                        "real_tokens_per_timed_step": tokens_steps, "mean_real_tokens_per_step": round(sum(tokens_steps) / len(tokens_steps), 1),
                        "Ni": net.last_counts["Ni"], "Nz": net.last_counts["Nz"], "rows_per_env": st.count(0, st.ROWS),
                        "instances_per_env": st.count(0, st.LIVE), "clip_dtype": str(cfg.clip_dtype), "llm_dtype": str(cfg.llava_dtype),
-                       "token_builder_dtype": "float32", "parallelism": f"episode-parallel x{a.gpus} (no data-path collective)",
+                       "token_builder_dtype": "float32", "parallelism": f"episode-parallel x{world} (no data-path collective)" + (" [test hook: ranks share cuda:0]" if shared_hook else ""),
                        "dense_backend": dict(D.BACKEND), "strict_hip": bool(D.STRICT),
                        "dense_dispatch_per_step": {k: round(v / a.steps, 2) for k, v in D.counts()["hip"].items()},
                        "fallbacks": int(sum(D.counts()["fallback"].values()))},
@@ -274,7 +332,7 @@ def main():
                          "step_total_tflop": round(fl["total"] / 1e12, 2), "step_frac_of_peak": round(fl["total"] / (ms * 1e-3) / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4),
                          "step_flop_split_tflop": {k: round(v / 1e12, 3) for k, v in fl.items() if k != "total"}},
         }
-        do_cpu = a.cpu_baseline == "on" or (a.cpu_baseline == "auto" and a.gpus == 1)
+        do_cpu = a.cpu_baseline == "on" or (a.cpu_baseline == "auto" and world == 1)
         if do_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, a.seed, B, a.warm_steps + a.warmup, lengths_seen[0])

@@ -51,6 +51,15 @@ def gather_metrics(sums: Dict[str, float], n_episodes: int, device="cpu") -> Dic
     return res
 
 
+def gather_objects(obj):
+    """Small per-rank records (device identity, own timing) of every rank, on every rank, in rank order."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, obj)
+        return out
+    return [obj]
+
+
 def max_over_ranks(x: float, device="cpu") -> float:
     if dist.is_initialized() and dist.get_world_size() > 1:
         t = torch.tensor([x], dtype=torch.float64, device=device)

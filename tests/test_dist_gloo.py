@@ -95,3 +95,14 @@ def test_two_rank_gradient_all_reduce_broadcast_and_nan_vote(tmp_path):
     (total / 2).backward()
     ref = torch.cat([p.grad.reshape(-1) for p in list(net.parameters()) + [extra]])
     assert torch.allclose(torch.tensor(outs[0]["grad"]), ref, atol=1e-6, rtol=1e-5)
+
+
+def test_bench_refuses_a_multi_gpu_number_it_cannot_measure():
+    """`python bench.py --gpus N` (N > 1) with no launcher on a machine without N GPUs, or under a launcher with a different
+    WORLD_SIZE, exits non-zero BEFORE allocating anything and prints no result line (round 3 printed N x one GPU's rate)."""
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "D3D_SHARE_DEVICE0")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "refusing" in out.stderr and "{" not in out.stdout
+    out = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=4" in out.stderr and "{" not in out.stdout

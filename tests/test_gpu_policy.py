@@ -192,3 +192,24 @@ def test_bench_two_ranks_share_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 8 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-2 * d["value"]   # whole-job aggregate
+    assert d["ranks_seen"] == 2 and [r["rank"] for r in d["per_rank"]] == [0, 1] and d["devices_seen"] == 1     # (the hook: both on cuda:0)
+    assert all(r["ms_per_step"] <= d["ms_per_step"] * 1.001 for r in d["per_rank"])                              # the line reports the slowest rank
+
+
+def test_bench_gpus_n_without_launcher_spawns_n_ranks_or_refuses():
+    """`python bench.py --gpus 2` with no launcher: on a box with fewer GPUs it exits non-zero and prints NO result line; with the
+    shared-device test hook it re-launches itself under torch.distributed.run and the line shows two ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--warm-steps", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "D3D_SHARE_DEVICE0", "D3D_DIST_BACKEND")}
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(base, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "refusing" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    out = subprocess.run(base, env=dict(env, D3D_SHARE_DEVICE0="1", D3D_DIST_BACKEND="gloo"), cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
