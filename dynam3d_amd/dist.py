@@ -93,7 +93,7 @@ def any_nan_vote(loss: torch.Tensor) -> bool:
     return bool(torch.isnan(v).any())
 
 
-def all_reduce_gradients(params, bucket_bytes: int = 64 << 20, average: bool = True, nan_to_zero: bool = True):
+def all_reduce_gradients(params, bucket_bytes: int = 64 << 20, average: bool = True, nan_to_zero: bool = True, assume_uniform: bool = False):
     """Data-parallel gradient reduction (DDP's role, PRE-TR:356-360, 512): the gradients of `params` (those that have one) are
     packed into float32 buckets of ~`bucket_bytes`, each bucket is ONE all_reduce (SUM), divided by the world size and scattered
     back into `.grad` in place.  `nan_to_zero` applies the reference's per-parameter NaN scrub (PRE-TR:513-515) after the
@@ -101,19 +101,22 @@ def all_reduce_gradients(params, bucket_bytes: int = 64 << 20, average: bool = T
     (the reference's `* 0.` terms exist for the same reason, PRE-FF:1340) -- but a parameter that has NO gradient on ANY rank
     keeps `.grad = None` (one extra all_reduce of a has-grad mask): the optimizer then skips it, as it does under the
     reference's DDP; materialising zeros would let AdamW decay and update moments of parameters the step did not touch.
-    Returns the number of collectives issued."""
+    `assume_uniform`: the caller guarantees that every rank has gradients for the same parameters (e.g. `pretrain_step`'s dummy
+    term); the mask exchange and its host synchronisation are skipped.
+    Returns the number of collectives issued (the mask exchange included)."""
     params = [p for p in params if p.requires_grad]
     world = dist.get_world_size() if dist.is_initialized() else 1
     has = None
-    if params and world > 1:
+    n_coll = 0
+    if params and world > 1 and not assume_uniform:
         has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=params[0].device)
         dist.all_reduce(has, op=dist.ReduceOp.SUM)
+        n_coll += 1
         has = (has > 0).tolist()
     elif params:
         has = [p.grad is not None for p in params]
     if has is not None:
         params = [p for p, h in zip(params, has) if h]
-    n_coll = 0
     if not params:
         return n_coll
     bucket, size = [], 0

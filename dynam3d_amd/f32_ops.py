@@ -32,7 +32,13 @@ def _stream():
 class F32Ops:
     # The float32 GEMMs run as split-precision fp16 MFMAs (hi hi + hi lo + lo hi, float32 accumulation: csrc/f32x3_kernels.hip) --
     # float32 accuracy at 16-bit matrix rate.  D3D_F32_SPLIT=0 (or F32Ops.SPLIT = False) selects the v_mfma_f32_16x16x4_f32 kernel.
+    # RANGE CONTRACT of the split kernel: |operand| < 65504 (the hi half is an fp16), and an element below ~2^-13 keeps only its hi half
+    # (its lo half falls into fp16's subnormals): absolute error <= 2^-25 per such element, invisible next to O(1) elements of the same
+    # dot product -- which is what the token builder feeds it (LayerNorm'ed activations, unit-norm CLIP features, metres).  D3D_F32_CHECK=1
+    # (or F32Ops.CHECK = True; on in the golden-trajectory GPU tests) verifies every output of the split kernel to be finite -- a host
+    # synchronisation per GEMM, so a debug switch, not the default.
     SPLIT = os.environ.get("D3D_F32_SPLIT", "1") != "0"
+    CHECK = os.environ.get("D3D_F32_CHECK", "0") == "1"
     KPAD = 32                                        # both kernels take K % 32 == 0 (the float32 one needs 16)
 
     def __init__(self):
@@ -87,6 +93,9 @@ class F32Ops:
             epi = "bias_gelu" if act == "gelu" else "bias"
         gemm = self.lib.d3d_gemm_nt_f32x3 if self.SPLIT else self.lib.d3d_gemm_nt_f32
         _lib.check(gemm(_p(x), _p(wp), _p(y), _p(b), _p(residual), M, N, Kp, x.stride(0), Kp, N, EPI[epi], _stream()))
+        if self.CHECK and self.SPLIT and not bool(torch.isfinite(y).all()):
+            raise FloatingPointError(f"d3d_gemm_nt_f32x3: non-finite output for x {tuple(x.shape)} (max |x| {float(x.abs().max()):.3g}), w {tuple(w.shape)} "
+                                     f"(max |w| {float(w.abs().max()):.3g}): operands outside the split kernel's fp16 range; set D3D_F32_SPLIT=0")
         return y
 
     def layer_norm(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None, gelu: bool = False) -> torch.Tensor:

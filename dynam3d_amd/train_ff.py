@@ -257,7 +257,9 @@ class FFTrainer:
     @torch.enable_grad()
     def merge(self, pools, slot_of_pair, pe, ps_, pj, pair_inst, n_envs):
         """(environment pe, segment ps_, proposal pj) pairs with instance row pair_inst.  Returns (pairs, 2) logits that make the memory merge
-        by GROUND TRUTH when GT ids exist (PRE-FF:1031-1035), else by the discriminator's argmax (PRE-FF:1063)."""
+        by GROUND TRUTH when GT ids exist (PRE-FF:1031-1035); in training mode WITHOUT a GT point cloud the reference sets `merge_target`
+        to zeros (PRE-FF:1061-1062): nothing merges, every segment becomes a new instance (the argmax is the `is_training=False`
+        branch, PRE-FF:1064) -- the returned logits force exactly that."""
         m, c = self.model, self.cur
         dev = c["pred"].device
         g = c["inv"].index_select(0, (pe * c["n_max"] + ps_).long())
@@ -266,7 +268,8 @@ class FFTrainer:
         x = torch.cat([f3, c["pred"].index_select(0, g), c["cen"].index_select(0, g) - p3], -1)       # [ft_3d, ft_2d, position offset] (PRE-FF:1023-1026)
         logits = m.merge_logits(x)
         if c["gt"] is None:
-            return logits.detach()
+            no = torch.zeros((logits.shape[0],), device=logits.device)
+            return torch.stack([1.0 - no, no], -1)                                                     # argmax = "do not merge" for every proposal
         gt3 = torch.stack([self._slot_gt(int(s), pools)[int(i)] for s, i in zip(slot_of_pair.tolist(), pair_inst.tolist())]).to(dev)
         target = (gt3 == c["gt"].index_select(0, g)).long()
         for j in range(n_envs):                                                                        # one cross-entropy per (environment, view)
@@ -313,7 +316,7 @@ class FFTrainer:
 
 def pretrain_step(ff, trainer: FFTrainer, optimizer, update_kwargs: dict, clip_value: float = 10.0) -> dict:
     """One optimisation step (PRE-TR:479-526) on `ff` (a `Feature_Fields(variant="pretrain")`): forward with loss collection, NaN vote over
-    the ranks, backward, NaN scrub, value clipping, gradient all-reduce, optimizer step; the updated weights are copied into the
+    the ranks, backward, gradient all-reduce (average), NaN scrub, value clipping, optimizer step; the updated weights are copied into the
     inference-path modules of `ff`.  Returns {'loss', 'sim_loss', 'segm_loss', 'skipped', 'collectives'}."""
     optimizer.zero_grad(set_to_none=True)
     trainer.begin()
@@ -326,13 +329,13 @@ def pretrain_step(ff, trainer: FFTrainer, optimizer, update_kwargs: dict, clip_v
         return out
     loss.backward()
     params = list(trainer.model.parameters())
-    for p in params:                                                   # PRE-TR:513-515
-        if p.grad is not None:
-            torch.nan_to_num_(p.grad, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
-    torch.nn.utils.clip_grad_value_(params, clip_value)                # PRE-TR:517
     zero = lambda p: torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()
-    trainer.local_grads = {k: zero(p) for k, p in zip(trainer.model.names, trainer.model.plist)}      # (kept for the tests)
-    out["collectives"] = DD.all_reduce_gradients(params, nan_to_zero=False)
+    trainer.local_grads = {k: zero(p) for k, p in zip(trainer.model.names, trainer.model.plist)}      # this rank's own, raw (kept for the tests)
+    # The reference runs backward under DDP (PRE-TR:356-360, 512): gradients are ALREADY averaged over the ranks when it scrubs NaNs
+    # (PRE-TR:513-515) and clips (PRE-TR:517).  Same order here: average -> scrub -> clip.  A NaN on one rank therefore zeroes that element
+    # on EVERY rank (NaN survives the sum), and clip(mean(g_r)), not mean(clip(g_r)), reaches the optimizer.
+    out["collectives"] = DD.all_reduce_gradients(params, average=True, nan_to_zero=True)
+    torch.nn.utils.clip_grad_value_(params, clip_value)                # PRE-TR:517
     trainer.last_grads = {k: zero(p) for k, p in zip(trainer.model.names, trainer.model.plist)}
     optimizer.step()
     sync_weights(ff, trainer.model)

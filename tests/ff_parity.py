@@ -11,6 +11,15 @@ from tests.test_oracle_golden import check_env_against_golden
 
 def run_case(name, ops, device, on_step=None, max_steps=None, m_cap=4096, z_cap=2048):
     """max_steps: row-pool capacity in steps (default: the whole trajectory fits); smaller values make the pools GROW mid-episode."""
+    from dynam3d_amd.f32_ops import F32Ops
+    check_before, F32Ops.CHECK = F32Ops.CHECK, str(device) != "cpu"      # every split-precision float32 GEMM output verified finite (f32_ops.py)
+    try:
+        return _run_case(name, ops, device, on_step, max_steps, m_cap, z_cap)
+    finally:
+        F32Ops.CHECK = check_before
+
+
+def _run_case(name, ops, device, on_step, max_steps, m_cap, z_cap):
     case = TRAJ_CASES[name]
     g = load(f"g4_{name}.npz")
     sd = synth_state_dict(ff_param_spec(), seed=0)
