@@ -243,6 +243,12 @@ def main():
         obs, pos, hd, segm = frames[i]
         return net.forward_logits(obs, instr, pos, hd, patch_segm=segm)
 
+    hp = None
+    if os.environ.get("D3D_BENCH_HP_STREAM") == "1":
+        # experiment knob: the step's main stream at HIGH priority, so that the llava tower on the (default-priority) side stream only
+        # fills what the critical path leaves idle (DESIGN.md section 8 "stream priorities")
+        hp = torch.cuda.Stream(device=dev, priority=-1)
+        torch.cuda.set_stream(hp)
     for i in range(a.warm_steps + a.warmup):
         run(i)
     torch.cuda.synchronize()

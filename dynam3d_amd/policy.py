@@ -93,6 +93,35 @@ class SyntheticTokenizer(PromptTokenizer):
         return " ".join(inv.get(int(i), "\n" if int(i) == self.NEWLINE else f"<{int(i)}>") for i in ids)
 
 
+class ActionGrammarTokenizer(SyntheticTokenizer):
+    """`SyntheticTokenizer` whose `decode` renders a GENERATED id sequence as a sentence of the policy's action language
+    ("turn left 2 steps, move 3 steps." / "stop.", VLN-POL:294-327).  No trained llava weights exist offline, so the tokens the LM
+    emits with seeded random weights mean nothing; this grammar gives the closed loop of config[3] (rollout.py) sentences that
+    `convert_text_to_action` can act on -- every branch reachable: left / right turns of 0-4 steps, moves of 0-4 steps, a capped
+    5-step turn (no move), stop, and a malformed sentence (-> -100 -> stop, like the trainer treats it, VLN-TR:695-696).
+    A function of the ids only: the same tokens give the same sentence everywhere."""
+
+    def __init__(self, vocab: int = 32064, add_bos: bool = True, stop_mod: int = 24):
+        super().__init__(vocab, add_bos)
+        self.stop_mod = stop_mod
+
+    def decode(self, ids: Sequence[int]) -> str:
+        end = self.SPECIAL["<|end|>"] % self.vocab
+        ids = [int(i) for i in ids]
+        if end in ids:
+            ids = ids[: ids.index(end)]
+        if not ids:
+            return "stop."
+        h = zlib.crc32(np.asarray(ids, np.int64).tobytes())            # all generated ids decide, well mixed
+        a = h % self.stop_mod
+        if a == 0:
+            return "stop."
+        if a == 1:
+            return "turn around and go back"                           # malformed on purpose
+        side = "left" if (h >> 8) & 1 == 0 else "right"
+        return f"turn {side} {(h >> 12) % 6} steps, move {(h >> 20) % 5} steps."
+
+
 @dataclass
 class PolicyConfig:
     vit: VitConfig = field(default_factory=VitConfig)

@@ -81,3 +81,66 @@ def nearest_resize_indices(src: int, dst: int) -> np.ndarray:
     """cv2.resize(INTER_NEAREST) source index rule (VLN-POL:339): floor(dst_i * src/dst), clamped."""
     idx = np.floor(np.arange(dst) * (src / dst)).astype(np.int64)
     return np.minimum(idx, src - 1)
+
+
+class ClosedLoopEpisodes:
+    """Synthetic stand-in for the Habitat side of `RLTrainer.rollout` (VLN-TR:624-633, 702-719): every environment has a pose that the
+    POLICY'S OWN ACTIONS move.  `observe()` returns the frame at the current poses (`get_agent_info`: position, heading + the RGB-D
+    sensors -- seeded images, the same statistics as `SyntheticEpisodes`); `step(actions)` applies the trainer's HIGHTOLOW action
+    (VLN-TR:713-719): rotate by `angle` (radians, counter-clockwise) and move `distance` metres forward, or ends the episode for a
+    stop action.  A synthetic goal 4-7 m from the start gives the reference's metrics something to measure (VLN-TR:735-748:
+    distance_to_goal, success = final distance <= 3 m, oracle_success, path_length, spl)."""
+
+    def __init__(self, n_envs: int, seed: int = 0, image_hw: int = 224, depth_hw: int = 224, n_blocks: int = 4, grid: int = 24):
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+        self.image_hw, self.depth_hw, self.grid, self.n_blocks = image_hw, depth_hw, grid, n_blocks
+        self.ids = list(range(n_envs))                                  # episode ids of the environments still running
+        self.pos = [np.array([self.rng.uniform(-2, 2), 0.0, self.rng.uniform(-2, 2)], np.float64) for _ in range(n_envs)]
+        self.head = [float(self.rng.uniform(0, 2 * math.pi)) for _ in range(n_envs)]
+        ga, gd = self.rng.uniform(0, 2 * math.pi, n_envs), self.rng.uniform(4.0, 7.0, n_envs)
+        self.goal = [self.pos[i] + np.array([gd[i] * math.cos(ga[i]), 0.0, gd[i] * math.sin(ga[i])]) for i in range(n_envs)]
+        self.path = [[p.copy()] for p in self.pos]
+        self.steps = [0] * n_envs
+
+    @property
+    def num_envs(self) -> int:
+        return len(self.ids)
+
+    def observe(self) -> Frame:
+        B, rng = self.num_envs, self.rng
+        rgb = rng.integers(0, 256, size=(B, self.image_hw, self.image_hw, 3), dtype=np.uint8)
+        depth = rng.uniform(0.05, 0.5, size=(B, self.depth_hw, self.depth_hw, 1)).astype(np.float32)
+        depth[rng.random(size=depth.shape) < 0.01] = 0.0
+        blk = self.grid // self.n_blocks
+        segm = np.zeros((B, 1, self.grid, self.grid), np.int64)
+        for b in range(B):
+            segm[b, 0] = np.kron(rng.permutation(self.n_blocks ** 2).reshape(self.n_blocks, self.n_blocks), np.ones((blk, blk), np.int64))
+        return Frame(rgb=rgb, depth=depth, positions=[p.copy() for p in self.pos], headings=list(self.head), patch_segm=segm)
+
+    def step(self, actions):
+        """actions[b] = None (stop, env action 0) or (angle rad CCW, distance m) (env action 4, VLN-TR:713-719).  Returns (dones, infos);
+        finished environments are REMOVED (the trainer's `envs.pause_at(i)`, VLN-TR:779-781), so indices shift like the trainer's."""
+        dones, infos = [], []
+        for b, a in enumerate(actions):
+            self.steps[b] += 1
+            if a is None:
+                d = [float(np.linalg.norm(p - self.goal[b])) for p in self.path[b]]
+                pl = float(sum(np.linalg.norm(q - p) for p, q in zip(self.path[b][:-1], self.path[b][1:])))
+                ok = 1.0 if d[-1] <= 3.0 else 0.0
+                infos.append(dict(episode_id=self.ids[b], steps_taken=self.steps[b], distance_to_goal=d[-1], success=ok,
+                                  oracle_success=1.0 if min(d) <= 3.0 else 0.0, path_length=pl, collisions=0.0,
+                                  spl=ok * d[0] / max(d[0], pl, 1e-9), ndtw=0.0, sdtw=0.0))
+                dones.append(True)
+                continue
+            angle, dist = a
+            self.head[b] = float((self.head[b] + angle) % (2 * math.pi))
+            # habitat: heading counter-clockwise about +y, forward = -z rotated by the heading (the convention of SyntheticEpisodes)
+            self.pos[b] = self.pos[b] + np.array([-dist * math.sin(self.head[b]), 0.0, -dist * math.cos(self.head[b])])
+            self.path[b].append(self.pos[b].copy())
+            dones.append(False)
+            infos.append(None)
+        for b in reversed(range(len(actions))):
+            if dones[b]:
+                for lst in (self.ids, self.pos, self.head, self.goal, self.path, self.steps):
+                    lst.pop(b)
+        return dones, infos
