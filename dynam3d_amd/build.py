@@ -25,9 +25,8 @@ HIP_SOURCES = [
     ("f32_kernels.hip", ["-ffp-contract=off"]),
     ("f32x3_kernels.hip", ["-ffp-contract=off"]),
     ("gemm_kernels.hip", ["-ffp-contract=fast"]),
-    ("attn_kernels.hip", ["-ffp-contract=fast"]),
-    ("attn2_kernels.hip", ["-ffp-contract=fast"]),
     ("attn3_kernels.hip", ["-ffp-contract=fast"]),
+    ("decode_attn_kernels.hip", ["-ffp-contract=fast"]),
     ("decode_kernels.hip", ["-ffp-contract=fast"]),
     ("render_kernels.hip", ["-ffp-contract=off"]),
     ("mlp_kernels.hip", ["-ffp-contract=fast"]),

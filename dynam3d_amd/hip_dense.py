@@ -19,8 +19,6 @@ _lib.register("d3d_gemm_reserve_workspace", [vp])
 _lib.register("d3d_norm", [vp, vp, vp, vp, i32, i32, i64, i64, f32, i32, i32, vp])
 _lib.register("d3d_rope_inplace", [vp, vp, vp, i32, i32, i32, i32, i64, vp, i32, vp])
 _lib.register("d3d_set_attention", [vp, vp, i32, i32, i32, i32, vp, vp])
-_lib.register("d3d_flash_attention", [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp])
-_lib.register("d3d_flash_attention_v2", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, i32, vp])
 _lib.register("d3d_flash_attention_v3", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, i32, vp])
 _lib.register("d3d_flash_attention_v3_rope_q", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp])
 _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
@@ -229,32 +227,17 @@ class HipDense:
     def attention_ok(qkv, hd):
         return qkv.dtype in (torch.bfloat16, torch.float16) and hd in (64, 96) and qkv.is_contiguous()
 
-    V_TR = True    # True: V transposed by the LDS read inside the kernel (no workspace); False: pre-transposed V^T workspace (A/B, tests)
-    ATTN_V2 = os.environ.get("D3D_ATTN_V2", "1") != "0"   # csrc/attn2_kernels.hip (32x32x16 MFMA, double-buffered K/V); False: round 1/2's kernel
-    ATTN_V3 = os.environ.get("D3D_ATTN_V3", "1") != "0"   # csrc/attn3_kernels.hip (v2's arithmetic, LDS-DMA staging, bulk fragment prefetch); needs ATTN_V2
-
-    def _flash_v23(self):
-        return self.lib.d3d_flash_attention_v3 if self.ATTN_V3 else self.lib.d3d_flash_attention_v2
-
     def attention_qkv(self, qkv, n_heads, causal, seq_len=None, window=0):
         """qkv (B,S,3H,hd) contiguous fused projection -> (B,S,H,hd): flash attention straight off the projection buffer."""
         B, S, Ht, hd = qkv.shape
         out = torch.empty((B, S, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
-        if self.ATTN_V2:
-            _lib.check(self._flash_v23()(_p(qkv), _p(out), B, S, n_heads, hd, Ht * hd, S * Ht * hd, 0, n_heads, 2 * n_heads, 1 if causal else 0,
-                                                       S if seq_len is None else seq_len, None, window, 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
-            return out
-        if window:
-            raise ValueError("the sliding window needs the v2 attention kernel")
-        vt = None if self.V_TR else torch.empty((B, n_heads, hd, (S + 63) // 64 * 64), dtype=qkv.dtype, device=qkv.device)
-        _lib.check(self.lib.d3d_flash_attention(_p(qkv), _p(out), _p(vt), B, S, n_heads, hd, Ht * hd, S * Ht * hd, 0, n_heads, 2 * n_heads,
-                                                1 if causal else 0, S if seq_len is None else seq_len, None,
-                                                0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
+        _lib.check(self.lib.d3d_flash_attention_v3(_p(qkv), _p(out), B, S, n_heads, hd, Ht * hd, S * Ht * hd, 0, n_heads, 2 * n_heads, 1 if causal else 0,
+                                                   S if seq_len is None else seq_len, None, window, 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
         return out
 
     def can_fuse_rope_q(self):
-        """The v3 attention kernel can rotate the queries itself (d3d_flash_attention_v3_rope_q)."""
-        return self.ATTN_V2 and self.ATTN_V3
+        """The attention kernel can rotate the queries itself (d3d_flash_attention_v3_rope_q)."""
+        return True
 
     def attention_packed(self, qkv, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid=None, window=0, out=None, rope_q=None):
         """PACKED variable-length batch: qkv (T, 3H, hd) rows of sequence b = [cu[b], cu[b+1]) -> (T, H, hd).  Rows beyond
@@ -270,8 +253,6 @@ class HipDense:
             if n_valid < T:
                 out[n_valid:].zero_()
         if rope_q is not None:
-            if not self.can_fuse_rope_q():
-                raise RuntimeError("attention_packed(rope_q=...) needs the v3 kernel (D3D_ATTN_V2 / D3D_ATTN_V3 not disabled)")
             cos, sin = rope_q                                     # (positions >= max_len, hd / 2) float32, contiguous
             assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
             assert cos.shape[0] >= max_len and cos.shape[1] == hd // 2 and sin.shape == cos.shape
@@ -279,13 +260,6 @@ class HipDense:
                                                               1 if causal else 0, max_len, _p(cu_seqlens), window, _p(cos), _p(sin),
                                                               0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
             return out
-        if self.ATTN_V2:
-            _lib.check(self._flash_v23()(_p(qkv), _p(out), n_seq, max_len, n_heads, hd, Ht * hd, 0, 0, n_heads, 2 * n_heads, 1 if causal else 0,
-                                                       max_len, _p(cu_seqlens), window, 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
-            return out
-        if window:
-            raise ValueError("the sliding window needs the v2 attention kernel")
-        vt = None if self.V_TR else torch.empty((n_seq, n_heads, hd, (max_len + 63) // 64 * 64), dtype=qkv.dtype, device=qkv.device)
-        _lib.check(self.lib.d3d_flash_attention(_p(qkv), _p(out), _p(vt), n_seq, max_len, n_heads, hd, Ht * hd, 0, 0, n_heads, 2 * n_heads,
-                                                1 if causal else 0, max_len, _p(cu_seqlens), 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
+        _lib.check(self.lib.d3d_flash_attention_v3(_p(qkv), _p(out), n_seq, max_len, n_heads, hd, Ht * hd, 0, 0, n_heads, 2 * n_heads, 1 if causal else 0,
+                                                   max_len, _p(cu_seqlens), window, 0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
         return out

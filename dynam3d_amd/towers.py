@@ -288,7 +288,7 @@ class Phi3Decoder:
 
     def _check_lengths(self, lens, max_new_tokens: int = 0):
         """Prompts the kernels do not model.  The PREFILL masks Phi-3-mini's sliding attention window (every layer attends to the last
-        2047 keys only) inside the flash kernel (`d3d_flash_attention_v2(window=...)`); the KV-cache decode kernel does not, so generation
+        2047 keys only) inside the flash kernel (`d3d_flash_attention_v3(window=...)`); the KV-cache decode kernel does not, so generation
         is limited to prompt + new tokens <= 2047.  The reference's prompts are 2 + 576 + Ni + Nz + text ~ 0.8-1.4 k tokens."""
         longest = max(lens) + max_new_tokens
         if max_new_tokens and longest > self.SLIDING_WINDOW:

@@ -355,24 +355,14 @@ int32_t d3d_rope_inplace(void* qkv_d, const float* cos_d, const float* sin_d, in
 /* out[m,i] = up * silu(gate) for a plain [gate(I) | up(I)] projection output */
 int32_t d3d_swiglu(const void* gate_up_d, void* out_d, int64_t rows, int32_t I, int32_t dtype, void* stream);
 /* fused (flash) self-attention forward over a fused QKV projection buffer (clip/model.py:171-183 MultiheadAttention,
- * HF CLIP / Phi-3 attention): qkv (B,S,Htot,hd) 16-bit, q/k/v heads start at q_off/k_off/v_off; strides in elements;
- * out (B,S,H,hd); hd in {64,96}; keys >= seq_len are masked; causal = lower-triangular. */
-int32_t d3d_flash_attention(const void* qkv_d, void* out_d, void* vt_scratch_d /* NULL: V transposed by the LDS read inside the kernel (default); or a (B,H,hd,ceil64(S)) 16-bit workspace for the pre-transposing variant */,
-                            int32_t B, int32_t S, int32_t H,
-                            int32_t head_dim, int64_t row_stride,
-                            int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
-                            const int32_t* cu_seqlens_d /* optional (B+1): packed variable-length batch */, int32_t dtype, void* stream);
-/* Second-generation kernel behind the same contract (csrc/attn2_kernels.hip: 32x32x16 MFMA tiles, one query column per lane pair,
- * K/V double-buffered in LDS with one barrier per key tile, masked 32-key blocks of diagonal tiles skipped; the default of the Python
- * host since round 3, d3d_flash_attention stays as the A/B baseline).  `window` > 0 (causal only): a query attends to its last `window`
- * keys, itself included -- HF's sliding-window mask (Phi-3-mini-4k: 2047; transformers 4.46 modeling_phi3.py
- * `_prepare_4d_causal_attention_mask_with_cache_position`: key <= query - window is masked); 0 = no window. */
-int32_t d3d_flash_attention_v2(const void* qkv_d, void* out_d, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride,
-                               int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
-                               const int32_t* cu_seqlens_d /* optional (B+1): packed variable-length batch */, int32_t window, int32_t dtype,
-                               void* stream);
-/* Same contract and results layout as d3d_flash_attention_v2; K/V tiles staged by LDS-DMA (no VGPR round trip) and all fragment reads of a
- * tile issued a phase ahead (csrc/attn3_kernels.hip).  The host's default (D3D_ATTN=2 / 1 select the older kernels for A/B runs). */
+ * HF CLIP / Phi-3 attention; csrc/attn3_kernels.hip): qkv (B,S,Htot,hd) 16-bit, q/k/v heads start at q_off/k_off/v_off; strides in
+ * elements; out (B,S,H,hd); hd in {64,96}; keys >= seq_len are masked; causal = lower-triangular.  cu_seqlens_d (optional, B+1 ints):
+ * PACKED variable-length batch -- sequence b occupies rows [cu[b], cu[b+1]) of qkv / out, S is then the longest sequence and
+ * batch_stride / seq_len are ignored.  `window` > 0 (causal only): a query attends to its last `window` keys, itself included -- HF's
+ * sliding-window mask (Phi-3-mini-4k: 2047; transformers 4.46 modeling_phi3.py `_prepare_4d_causal_attention_mask_with_cache_position`:
+ * key <= query - window is masked); 0 = no window.  32x32x16 MFMA tiles, one query column per lane pair, K/V tiles staged by LDS-DMA and
+ * all fragment reads of a tile issued a phase ahead, XCD-aware grid.  (Rounds 1-3 exported two earlier kernels, d3d_flash_attention and
+ * d3d_flash_attention_v2, as A/B baselines; retired in round 4, measurements in DESIGN.md section 4b.) */
 int32_t d3d_flash_attention_v3(const void* qkv_d, void* out_d, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride,
                                int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
                                const int32_t* cu_seqlens_d, int32_t window, int32_t dtype, void* stream);

@@ -256,18 +256,9 @@ def test_set_attention_varlen(hd):
             assert float(cls[off[g] + 1:off[g + 1]].abs().sum()) == 0.0
 
 
-ATTN_VARIANTS = {"v3": (True, True, True), "v2": (True, True, False), "v1_tr": (False, True, False), "v1_workspace": (False, False, False)}      # (ATTN_V2, V_TR, ATTN_V3)
-
-
-@pytest.mark.parametrize("variant", list(ATTN_VARIANTS))
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 4e-3), (torch.float16, 6e-4)])
-def test_flash_attention_vs_fp32_reference(hd, dt, tol, variant, monkeypatch):
-    """d3d_flash_attention_v2 / d3d_flash_attention (head_dim 64/96, causal/full, ragged S, masked tail) vs float32 SDPA on the same 16-bit
-    inputs.  Variants: v2 = the 32x32x16 kernel (default); v1_tr / v1_workspace = round 1/2's kernel with V transposed by
-    ds_read_b64_tr_b16 / through a pre-transposed V^T workspace."""
-    monkeypatch.setattr(type(hd), "ATTN_V2", ATTN_VARIANTS[variant][0])
-    monkeypatch.setattr(type(hd), "V_TR", ATTN_VARIANTS[variant][1])
-    monkeypatch.setattr(type(hd), "ATTN_V3", ATTN_VARIANTS[variant][2])
+def test_flash_attention_vs_fp32_reference(hd, dt, tol):
+    """d3d_flash_attention_v3 (head_dim 64/96, causal/full, ragged S, masked tail) vs float32 SDPA on the same 16-bit inputs."""
     torch.manual_seed(4)
     for (B, H, S, d, causal) in [(2, 3, 577, 64, False), (2, 4, 900, 96, True), (1, 2, 130, 96, True), (3, 2, 64, 64, True), (1, 1, 1, 96, True), (2, 2, 333, 96, False)]:
         qkv = (torch.randn(B, S, 3 * H, d, device="cuda") * 1.5).to(dt)
@@ -286,16 +277,12 @@ def test_flash_attention_vs_fp32_reference(hd, dt, tol, variant, monkeypatch):
     assert rel(hd.attention_qkv(qkv, H, True).float(), ref) < tol
 
 
-@pytest.mark.parametrize("variant", list(ATTN_VARIANTS))
 @pytest.mark.parametrize("causal", [True, False])
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 6e-3), (torch.float16, 1e-3)])
-def test_flash_attention_packed_ragged(hd, dt, tol, causal, variant, monkeypatch):
+def test_flash_attention_packed_ragged(hd, dt, tol, causal):
     """Packed variable-length batch (cu_seqlens): sequences of 1 token, below / at / just above a 128-row query block and a
     64-key tile, odd and even block counts (the causal kernel pairs the longest block of a sequence with its shortest), padding
     rows after the last sequence.  Reference: fp32 softmax attention per sequence.  Tolerance = 16-bit output rounding + 16-bit P."""
-    monkeypatch.setattr(type(hd), "ATTN_V2", ATTN_VARIANTS[variant][0])
-    monkeypatch.setattr(type(hd), "V_TR", ATTN_VARIANTS[variant][1])
-    monkeypatch.setattr(type(hd), "ATTN_V3", ATTN_VARIANTS[variant][2])
     torch.manual_seed(5)
     H, d = 4, 96
     lens = [1, 63, 128, 129, 200, 385, 640, 705]
@@ -314,15 +301,11 @@ def test_flash_attention_packed_ragged(hd, dt, tol, causal, variant, monkeypatch
     assert float(out[T:].abs().max()) == 0.0                     # padding rows untouched
 
 
-@pytest.mark.parametrize("variant", list(ATTN_VARIANTS))
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_flash_attention_bitwise_repeatable(hd, dt, variant, monkeypatch):
+def test_flash_attention_bitwise_repeatable(hd, dt):
     """The same launch twenty times gives the same bits.  (Round 3: a three-input maximum written as inline asm read the score
     accumulators without the wait states a VALU needs after the MFMA that wrote them -- the hazard recogniser does not look inside
     asm -- and the last bits of every query block after the first changed from launch to launch while every tolerance test passed.)"""
-    monkeypatch.setattr(type(hd), "ATTN_V2", ATTN_VARIANTS[variant][0])
-    monkeypatch.setattr(type(hd), "V_TR", ATTN_VARIANTS[variant][1])
-    monkeypatch.setattr(type(hd), "ATTN_V3", ATTN_VARIANTS[variant][2])
     torch.manual_seed(9)
     for H, d, lens in ((32, 96, [37, 211, 129, 64, 5, 90, 300, 17]), (8, 96, [828, 826, 1072]), (16, 64, [577, 577])):
         T = sum(lens)

@@ -3,7 +3,7 @@ that no launch finds its keys in a cache), us per launch and TB/s for 1 / 2 / 4 
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from dynam3d_amd.hip_dense import HipDense

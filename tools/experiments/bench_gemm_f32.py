@@ -1,6 +1,6 @@
 """d3d_gemm_nt_f32 (fp32 MFMA) against torch's float32 F.linear (hipBLASLt sgemm) on the token builder's shapes."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 from dynam3d_amd.f32_ops import F32Ops

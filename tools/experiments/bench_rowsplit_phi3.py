@@ -1,7 +1,7 @@
 """Phi-3 o_proj / down_proj / qkv at M = 6400 .. 6912: the library's choice (one round of 256-tiles + a K-split tail + fix-up launch) against a ROW split:
 the 256 x 256 kernel on the row tiles that fill whole rounds, the 128 x 128 kernel on the remaining rows (no partial sums, no fix-up)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dynam3d_amd.hip_dense import HipDense
 hd = HipDense()

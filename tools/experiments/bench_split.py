@@ -1,6 +1,6 @@
 """Split-K tail (tile 258) vs whole-tile (257) vs 128x128 (128) on shapes with a partial last round."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dynam3d_amd.hip_dense import HipDense
 hd = HipDense()

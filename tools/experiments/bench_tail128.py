@@ -1,6 +1,6 @@
 """gate_up (N = 16384, K = 3072, fused SwiGLU) at row counts around the step's: default dispatcher vs D3D_GEMM_TAIL128=0 (set by the caller)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dynam3d_amd.hip_dense import HipDense, interleave_gate_up
 hd = HipDense()

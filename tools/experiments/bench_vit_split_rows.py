@@ -1,7 +1,7 @@
 """ViT fc1 / fc2 / out-proj at M = 4616: the 256 x 256 kernel on the rows that make exactly one round of 256 tiles + the 128-tile kernel on the
 rest, against the library's own choice."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dynam3d_amd.hip_dense import HipDense
 hd = HipDense()

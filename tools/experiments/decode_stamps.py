@@ -5,7 +5,7 @@ import sys
 
 os.environ["D3D_DECODE_PERSISTENT"] = "1"
 os.environ["D3D_DECODE_DEBUG"] = str(32 | int(sys.argv[1]) if len(sys.argv) > 1 else 32)
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from dynam3d_amd import _lib, dense_ops as D

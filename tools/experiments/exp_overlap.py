@@ -2,7 +2,7 @@
 prefix) hides under a Phi-3 prefill running on another stream?  Steady state of: [prefill of frame i-1's prompt on stream A] || [build_inputs of
 frame i on the main stream], against the serial step."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dynam3d_amd import dense_ops as D
 from dynam3d_amd.policy import Dynam3D_VLN, PolicyConfig, synth_policy_weights

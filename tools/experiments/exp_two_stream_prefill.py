@@ -1,7 +1,7 @@
 """Experiment: the packed Phi-3 prefill of 8 prompts as ONE launch sequence against TWO half-batches (4 prompts each) on two HIP streams, so that
 the partial last rounds / split-K tails / small kernels of one half run beside the other half's GEMMs."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from dynam3d_amd import dense_ops as D
 from dynam3d_amd.towers import Phi3Config, Phi3Decoder, phi3_param_spec

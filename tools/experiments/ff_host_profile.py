@@ -1,6 +1,6 @@
 """cProfile of the host side of one warm 3D-token update (B = 8) running on the GPU: where do the 4 ms of wall time go?"""
 import cProfile, os, pstats, sys, io
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from dynam3d_amd.feature_fields import Feature_Fields
 from dynam3d_amd.weights import ff_param_spec, synth_state_dict

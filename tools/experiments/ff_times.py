@@ -1,6 +1,6 @@
 """Where does Feature_Fields.update_feature_fields spend its time?  Wraps every ops/dense/state call with a synchronised timer."""
 import os, sys, time, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from dynam3d_amd.feature_fields import Feature_Fields
 from dynam3d_amd.weights import ff_param_spec, synth_state_dict

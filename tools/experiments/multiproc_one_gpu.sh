@@ -3,7 +3,7 @@
 # because RCCL refuses duplicate devices -- full-length episodes.  What it measures: the host-side cost of one rank (wall and CPU
 # milliseconds per batch step) under N concurrent ranks on one host, and whether N ranks sharing a GPU still add up to the
 # single-rank throughput (they must: the GPU is the shared resource; anything lost is host contention or scheduling).
-# usage: tools/multiproc_one_gpu.sh [steps=30] [list of N = "1 2 4"]
+# usage: tools/experiments/multiproc_one_gpu.sh [steps=30] [list of N = "1 2 4"]
 STEPS=${1:-30}
 NS=${2:-"1 2 4"}
 export D3D_SHARE_DEVICE0=1 D3D_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0

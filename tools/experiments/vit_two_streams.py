@@ -1,7 +1,7 @@
 """Both vision towers concurrently on two HIP streams (as build_inputs runs them), per forced GEMM tile variant: what matters there is
 CU-time per GEMM, not the latency of an isolated launch (a partial last round is filled by the other tower's kernels)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dynam3d_amd import dense_ops as D
 from dynam3d_amd.hip_dense import HipDense
