@@ -706,10 +706,10 @@ int32_t launch(const void* A, const void* W, void* C, const void* bias, const vo
 // the row-statistics prologue cost 13-31 us per projection against 9 us for the separate norm launch; dropped.)
 // ================================================================================================
 // HALF: 16 instead of 32 columns per workgroup (twice as many workgroups: the narrow o_proj / down_proj then cover 192 CUs, not 96)
-// NORM: X is the RAW residual stream and the kernel applies HF Phi3RMSNorm (gain `nw`, float32) to it on the fly -- every workgroup
-// recomputes the <= 16 row statistics (wave per row, the lane / chunk order of k_norm: bit-identical to d3d_norm) while its first
-// weight fragments are in flight, and normalises the activation fragments as it loads them.  Saves the d3d_norm launch in front of
-// the qkv / gate_up / lm_head projections of a decode token (64 + 1 launches of ~7 us each per token).
+// NORM: X is the RAW residual stream and the kernel applies HF Phi3RMSNorm (gain `nw`, float32) to it -- every workgroup normalises
+// the <= 16 rows once into LDS (wave per row, the lane / chunk order of k_norm: bit-identical to d3d_norm) while its first weight
+// fragments are in flight, and the K loop reads its activation fragments from there.  Saves the d3d_norm launch in front of the
+// qkv / gate_up / lm_head projections of a decode token (64 + 1 launches of ~7 us each per token).
 template <bool BF16, int EPI, bool HALF, bool NORM = false>
 __global__ void __launch_bounds__(1024)
 k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
@@ -735,10 +735,15 @@ k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, ui
             if constexpr (!HALF) b[u] = *reinterpret_cast<const uint4*>(w1 + (st + u) * 32);
         }
     }
-    const uint16_t* xr = X + (int64_t)(fi < M ? fi : M - 1) * ldx + fg * 8;      // rows >= M: a duplicate, never stored
-    float rstd = 1.f;
+    const int xrow = fi < M ? fi : M - 1;                                           // rows >= M: a duplicate, never stored
+    const uint16_t* xr = X + (int64_t)xrow * ldx + fg * 8;
+    // NORM: the <= 16 rows are normalised ONCE per workgroup into LDS (x_hat stored 16-bit, times the gain, stored 16-bit: HF Phi3RMSNorm;
+    // statistics in k_norm's lane / chunk order: bit-identical to d3d_norm) while the first weight fragments are in flight; the K loop then
+    // reads its activation fragments from LDS and does nothing but stream weights.  (Round 2's version normalised every fragment inside
+    // the K loop -- gain loads + 16 conversions per step on the path that should only wait for weights: slower than the separate launch.)
+    const int XS = K + 8;                                                            // LDS row stride in elements (16 B pad: rows 4 banks apart)
+    uint16_t* xs = reinterpret_cast<uint16_t*>(sk_lds + NW * 2 * 64 * 4);
     if constexpr (NORM) {
-        float* rs = sk_lds + NW * 2 * 64 * 4;                                    // [16] behind the reduction buffer
         for (int r = wave; r < M; r += NW) {
             const uint16_t* row = X + (int64_t)r * ldx;
             float ss = 0.f;
@@ -753,27 +758,28 @@ k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, ui
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-            if (lane == 0) rs[r] = rsqrtf(ss / (float)K + eps);
+            const float rstd = rsqrtf(ss / (float)K + eps);
+            for (int c = 0; c < K / 512; ++c) {
+                const int off = c * 512 + lane * 8;
+                const uint4 raw = *reinterpret_cast<const uint4*>(row + off);
+                const float4 g0 = *reinterpret_cast<const float4*>(nw + off), g1 = *reinterpret_cast<const float4*>(nw + off + 4);
+                const float ww[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const uint16_t* h = reinterpret_cast<const uint16_t*>(&raw);
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    float a = to_f32<BF16>(h[j]) * rstd, b = to_f32<BF16>(h[j + 1]) * rstd;
+                    r16x2<BF16>(a, b);
+                    o[j >> 1] = pack2<BF16>(a * ww[j], b * ww[j + 1]);
+                }
+                *reinterpret_cast<uint4*>(xs + r * XS + off) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
         }
         __syncthreads();
-        rstd = rs[fi < M ? fi : M - 1];
     }
     auto xfrag = [&](int stp) -> uint4 {
-        uint4 raw = *reinterpret_cast<const uint4*>(xr + stp * 32);
-        if constexpr (NORM) {                                                    // weight * x_hat.to(dtype), both products stored 16-bit
-            const float4 w0 = *reinterpret_cast<const float4*>(nw + stp * 32 + fg * 8), w1 = *reinterpret_cast<const float4*>(nw + stp * 32 + fg * 8 + 4);
-            const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-            const uint16_t* h = reinterpret_cast<const uint16_t*>(&raw);
-            uint32_t o[4];
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                float a = to_f32<BF16>(h[j]) * rstd, b = to_f32<BF16>(h[j + 1]) * rstd;
-                r16x2<BF16>(a, b);
-                o[j >> 1] = pack2<BF16>(a * ww[j], b * ww[j + 1]);
-            }
-            raw = make_uint4(o[0], o[1], o[2], o[3]);
-        }
-        return raw;
+        if constexpr (NORM) return *reinterpret_cast<const uint4*>(xs + xrow * XS + stp * 32 + fg * 8);
+        else return *reinterpret_cast<const uint4*>(xr + stp * 32);
     };
     float4v acc0 = float4v{0.f, 0.f, 0.f, 0.f}, acc1 = float4v{0.f, 0.f, 0.f, 0.f};
     if (first) {
@@ -840,7 +846,22 @@ int32_t launch_skinny(const void* A, const void* W, void* C, const void* bias, c
     const int ntiles = half ? N / 16 : N / 32;
     int nwv = ntiles <= 256 ? 16 : (ntiles <= 512 ? 8 : 4);           // ~2000-4000 waves on the chip, K / 32 / nw steps each
     while (nwv > 1 && nsteps / nwv < 2) nwv >>= 1;
-    const size_t sh = (size_t)nwv * 2 * 64 * 16 + 64;
+    const size_t sh = (size_t)nwv * 2 * 64 * 16 + (NORM ? (size_t)M * (K + 8) * 2 : 0);     // wave reduction buffer [+ the normalised rows]
+    if constexpr (NORM) {
+        if (sh > 160 * 1024) {
+            d3d_set_error_("d3d_gemm_nt_rmsnorm: rows x K does not fit the LDS");
+            return D3D_EINVAL;
+        }
+        static std::once_flag attr_once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(attr_once, [&] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<BF16, EPI, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if constexpr (EPI != EPI_SWIGLU)
+                if (attr_err == hipSuccess)
+                    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<BF16, EPI, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        D3D_HIP(attr_err);
+    }
     if (half) {
         if constexpr (EPI != EPI_SWIGLU)
             hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, true, NORM>), dim3(ntiles), dim3(nwv * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,

@@ -309,6 +309,7 @@ class Dynam3D_VLN(RefreshOnChange):
             _, grid = clip.forward(pixels)                                                    # (B*V,576,768) fp16, stays on device
         finally:
             clip.after_block = None
+        self.last_grid = grid                                                                 # (bench.py hands these to the CPU oracle's memory advance)
         # The frustum cull needs the depth and the stored rows, not the CLIP features: it runs -- with its host round trip for the
         # hit lists -- on a third stream UNDER the CLIP tower, which the host has only queued at this point.
         if delete_old_features:

@@ -39,8 +39,13 @@ modes = [("launch-per-op, 1 key range", {"D3D_DECODE_PERSISTENT": "0", "D3D_DECO
          ("launch-per-op, 2 key ranges", {"D3D_DECODE_PERSISTENT": "0", "D3D_DECODE_SPLIT": "2"}),
          ("launch-per-op, 4 key ranges", {"D3D_DECODE_PERSISTENT": "0", "D3D_DECODE_SPLIT": "4"}),
          ("launch-per-op, 8 key ranges", {"D3D_DECODE_PERSISTENT": "0", "D3D_DECODE_SPLIT": "8"}),
-         ("launch-per-op, default", {"D3D_DECODE_PERSISTENT": "0"}),
+         ("launch-per-op, default", {"D3D_DECODE_PERSISTENT": "0", "D3D_DECODE_FUSE_NORM": "0"}),
+         ("launch-per-op, RMSNorm fused into the GEMMs", {"D3D_DECODE_PERSISTENT": "0", "D3D_DECODE_FUSE_NORM": "1"}),
+         ("launch-per-op, default (again)", {"D3D_DECODE_PERSISTENT": "0", "D3D_DECODE_FUSE_NORM": "0"}),
+         ("launch-per-op, fused norm (again)", {"D3D_DECODE_PERSISTENT": "0", "D3D_DECODE_FUSE_NORM": "1"}),
          ("persistent kernel", {"D3D_DECODE_PERSISTENT": "1"})]
+if os.environ.get("BENCH_DECODE_QUICK") == "1":
+    modes = modes[4:8]
 for name, env in modes:
     os.environ.pop("D3D_DECODE_SPLIT", None)
     os.environ.update(env)
@@ -48,4 +53,4 @@ for name, env in modes:
     short = min(timed(2) for _ in range(4))
     long_ = min(timed(T) for _ in range(4))
     ms = (long_ - short) / (T - 2)
-    print(f"{name:32s} {ms:6.3f} ms per token  ({(weights_gb + kv_gb) / ms:5.2f} TB/s over {weights_gb:.2f} GB weights + {kv_gb:.2f} GB keys/values)", flush=True)
+    print(f"{name:48s} {ms:6.3f} ms per token  ({(weights_gb + kv_gb) / ms:5.2f} TB/s over {weights_gb:.2f} GB weights + {kv_gb:.2f} GB keys/values)", flush=True)
