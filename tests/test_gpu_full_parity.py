@@ -16,7 +16,10 @@ from tests.golden_io import GOLDEN_DIR
 
 pytestmark = pytest.mark.gpu
 
-MARGIN_RMS = 0.25        # a top-2 margin above this many logit-rms units is outside what the 16-bit band can flip (band ~1.7e-2 * sqrt(2) per pair)
+# When is a token DECIDED?  The band (lowp vs float32, g19) is ~1.73e-2 relative L2 over the vocabulary = a per-logit noise of ~0.0173 rms units;
+# the difference of two logits carries sqrt(2) of that (0.0245).  A top-2 margin above 5 of those sigmas cannot be flipped by 16-bit noise.
+# (With seeded random weights the logits are nearly flat -- the oracle's own margins are 0.006 ... 0.23 rms -- so most, not all, positions qualify.)
+MARGIN_RMS = 0.12
 
 
 def _rel(a, b):
