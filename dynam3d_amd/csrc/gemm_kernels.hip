@@ -742,7 +742,8 @@ k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, ui
     // reads its activation fragments from LDS and does nothing but stream weights.  (Round 2's version normalised every fragment inside
     // the K loop -- gain loads + 16 conversions per step on the path that should only wait for weights: slower than the separate launch.)
     const int XS = K + 8;                                                            // LDS row stride in elements (16 B pad: rows 4 banks apart)
-    uint16_t* xs = reinterpret_cast<uint16_t*>(sk_lds + NW * 2 * 64 * 4);
+    uint16_t* xs = reinterpret_cast<uint16_t*>(sk_lds);       // shares the LDS with the wave-reduction buffer (used only after the K loop):
+                                                              // 49 KB at 8 rows instead of 81 -- two 16-wave workgroups per CU either way
     if constexpr (NORM) {
         for (int r = wave; r < M; r += NW) {
             const uint16_t* row = X + (int64_t)r * ldx;
@@ -819,6 +820,7 @@ k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, ui
             acc1 = mfma16<BF16>(bw, x, acc1);
         }
     }
+    if constexpr (NORM) __syncthreads();                       // every wave is done reading the normalised rows the buffer below overlays
     red[(wave * 2 + 0) * 64 + lane] = acc0;
     red[(wave * 2 + 1) * 64 + lane] = acc1;
     __syncthreads();
@@ -846,7 +848,8 @@ int32_t launch_skinny(const void* A, const void* W, void* C, const void* bias, c
     const int ntiles = half ? N / 16 : N / 32;
     int nwv = ntiles <= 256 ? 16 : (ntiles <= 512 ? 8 : 4);           // ~2000-4000 waves on the chip, K / 32 / nw steps each
     while (nwv > 1 && nsteps / nwv < 2) nwv >>= 1;
-    const size_t sh = (size_t)nwv * 2 * 64 * 16 + (NORM ? (size_t)M * (K + 8) * 2 : 0);     // wave reduction buffer [+ the normalised rows]
+    const size_t sh_red = (size_t)nwv * 2 * 64 * 16, sh_x = NORM ? (size_t)M * (K + 8) * 2 : 0;
+    const size_t sh = sh_red > sh_x ? sh_red : sh_x;           // wave reduction buffer, overlaid on the normalised rows
     if constexpr (NORM) {
         if (sh > 160 * 1024) {
             d3d_set_error_("d3d_gemm_nt_rmsnorm: rows x K does not fit the LDS");

@@ -45,6 +45,19 @@ def alignment_loss(pred_inst, tgt_inst, pred_inst_sub, tgt_inst_sub, pred_zone: 
     return loss
 
 
+def render_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """PRE-TR:1056-1075: rendered novel-view patch features `pred` (views, rays, 768) against the CLIP patch features of the view's image
+    (2 x 2 average-pooled to the 12 x 12 ray grid): 2 x (1 - cosine) in the per-view mean-centred subspace, 5 x (1 - cosine), and the
+    symmetric InfoNCE over all rays / 5.  Norms carry the reference's + 1e-5."""
+    pred, target = pred.float(), target.float()
+    ps, ts = pred - pred.mean(1, keepdim=True), target - target.mean(1, keepdim=True)
+    ps, ts = _unit(ps, 1e-5), _unit(ts, 1e-5)
+    loss = (1.0 - (ps * ts).sum(-1)).mean() * 2.0
+    p, t = _unit(pred, 1e-5).reshape(-1, pred.shape[-1]), _unit(target, 1e-5).reshape(-1, target.shape[-1])
+    loss = loss + (1.0 - (p * t).sum(-1)).mean() * 5.0
+    return loss + contrastive_loss(p, t, 10.0) / 5.0
+
+
 def segmentation_loss(merge_logits: torch.Tensor, merge_target: torch.Tensor):
     """merge_logits (..., 2), merge_target (...) in {0, 1}.  Returns None when one class is absent (the reference then skips it)."""
     score = torch.softmax(merge_logits, dim=-1).reshape(-1, 2)

@@ -88,11 +88,13 @@ class FieldRenderer:
             self._pin_key = key
         return self._pin
 
-    def render(self, pools: Pools, slots: Sequence[int], n_rows: Sequence[int], batch_position, batch_heading, ops, debug=False,
-               batch_rot=None, batch_trans=None, view_intrinsic=None):
-        """-> (features (B,H,W,768) f32 unit-norm, positions (B,H,W,3), depth (B,H,W)[, debug dict]).
-        Habitat mode: `batch_position` / `batch_heading`.  Intrinsics mode (PRE-FF:505-515, 532-536): camera->world `batch_rot` /
-        `batch_trans` per env and the view-sized (fx, fy) of the last update."""
+    def front(self, pools: Pools, slots: Sequence[int], n_rows: Sequence[int], batch_position, batch_heading, ops, want_geom6=False,
+              batch_rot=None, batch_trans=None, view_intrinsic=None, raw_features=False):
+        """Everything in front of the networks (PRE-FF:494-615): rays, k = 4 KNN of every depth sample against the stored patches, importance
+        top-8 per ray, neighbour gather + 6-d relative geometry [+ position embedding].  Returns a dict: s16 (n_rays * S, K * 768) fp16 =
+        neighbour feature + Linear(6, 768) + LN of its geometry (fp16 add) -- or, with `raw_features`, the gathered features alone (the
+        training step evaluates the position embedding differentiably itself, train_render.py) --, geom6 (n_rays * S * K, 6) when asked for,
+        topk (n_rays, S), sidx, n_ranked, sample_xyz, ray, rel_dist16."""
         B, R, N, S, K = len(slots), self.R, self.N, self.n_imp, self.k
         dev, lib, st = self.dev, self.lib, self._stream
         i32t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(dev)
@@ -128,10 +130,30 @@ class FieldRenderer:
         ray_slot = i32t(np.repeat(np.asarray(slots), R))
         s16 = torch.empty((n_rays * S, K * FTS), dtype=torch.float16, device=dev)
         sample_xyz = torch.empty((n_rays, S, 3), dtype=torch.float32, device=dev)
-        geom6 = torch.empty((n_rays * S * K, 6), dtype=torch.float32, device=dev) if debug else None
+        geom6 = torch.empty((n_rays * S * K, 6), dtype=torch.float32, device=dev) if want_geom6 else None
+        if raw_features:
+            # zero Linear + zero LayerNorm bias: LN(0) * gain + 0 = 0, and the kernel's fp16 add leaves the gathered features untouched
+            if getattr(self, "_zero6", None) is None:
+                self._zero6 = (torch.zeros_like(self.w6), torch.zeros_like(self.b6), torch.ones_like(self.ln6[0]), torch.zeros_like(self.ln6[1]))
+            w6, b6, g6, be6 = self._zero6
+        else:
+            w6, b6, g6, be6 = self.w6, self.b6, self.ln6[0], self.ln6[1]
         _lib.check(lib.d3d_render_embed(_p(pools.rows_pos), _p(pools.rows_dir), _p(pools.rows_scale), _p(pools.rows_fts), pools.n_cap, _p(ray_slot),
                                         _p(ray_env), _p(ray), _p(topk), _p(sidx), _p(torch.from_numpy(pose3).to(dev)), _p(rel_dir), n_rays, R, N, S, K,
-                                        self.far, _p(self.w6), _p(self.b6), _p(self.ln6[0]), _p(self.ln6[1]), 1e-12, _p(s16), _p(geom6), _p(sample_xyz), st()))
+                                        self.far, _p(w6), _p(b6), _p(g6), _p(be6), 1e-12, _p(s16), _p(geom6), _p(sample_xyz), st()))
+        return dict(s16=s16, geom6=geom6, topk=topk, sidx=sidx, n_ranked=n_ranked, sample_xyz=sample_xyz, ray=ray, rel_dist16=rel_dist16, n_rays=n_rays, B=B)
+
+    def render(self, pools: Pools, slots: Sequence[int], n_rows: Sequence[int], batch_position, batch_heading, ops, debug=False,
+               batch_rot=None, batch_trans=None, view_intrinsic=None):
+        """-> (features (B,H,W,768) f32 unit-norm, positions (B,H,W,3), depth (B,H,W)[, debug dict]).
+        Habitat mode: `batch_position` / `batch_heading`.  Intrinsics mode (PRE-FF:505-515, 532-536): camera->world `batch_rot` /
+        `batch_trans` per env and the view-sized (fx, fy) of the last update."""
+        fr = self.front(pools, slots, n_rows, batch_position, batch_heading, ops, want_geom6=debug, batch_rot=batch_rot, batch_trans=batch_trans,
+                        view_intrinsic=view_intrinsic)
+        B, R, N, S, K = fr["B"], self.R, self.N, self.n_imp, self.k
+        dev, lib, st = self.dev, self.lib, self._stream
+        s16, geom6, topk, sidx, n_ranked, sample_xyz, ray, rel_dist16, n_rays = (fr[k] for k in ("s16", "geom6", "topk", "sidx", "n_ranked", "sample_xyz",
+                                                                                             "ray", "rel_dist16", "n_rays"))
         x = self.hd.gemm(s16, self.agg_w, self.agg_b, None, "bias")                              # PRE-FF:483 Linear(3072,768)
         x = self.hd.layer_norm(x, self.agg_ln[0], self.agg_ln[1], 1e-12)
         enc = self.encoder(x)                                                                    # (M,769) fp16   PRE-FF:484

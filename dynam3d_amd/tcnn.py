@@ -103,7 +103,10 @@ class _MlpFunction(torch.autograd.Function):
         ctx.net = net
         ctx.save_for_backward(*acts)                                 # (saved tensors: autograd detects `params` / activations modified in between)
         ctx.x_dtype = x.dtype
-        return h[:, : net.n_output_dims]
+        # `float32_grad_io`: hand the (fp16-valued) result out as float32, so that the gradient arrives here in float32 and is scaled by
+        # LOSS_SCALE BEFORE its cast to fp16 -- through an fp16 output tensor autograd would deliver an fp16 gradient, in which the 1e-6-sized
+        # entries of a mean-reduced loss are already flushed
+        return h[:, : net.n_output_dims].float() if net.float32_grad_io else h[:, : net.n_output_dims]
 
     @staticmethod
     def backward(ctx, dy):
@@ -169,6 +172,7 @@ class Network(torch.nn.Module):
             raise ValueError("the MFMA kernels need n_input_dims % 64 == 0 and n_neurons % 128 == 0 (the reference uses 768)")
         self.device = torch.device(device)
         self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
+        self.float32_grad_io = False             # see _MlpFunction.forward
         self.hd = HipDense()
         # rows of each layer in the flat vector / in the GEMM operand
         self._rows_flat = [self.dims[i + 1] for i in range(nh)] + [(n_output_dims + OUTPUT_PAD - 1) // OUTPUT_PAD * OUTPUT_PAD]

@@ -31,6 +31,7 @@ import torch.nn.functional as F
 from . import _lib
 from . import dist as DD
 from . import losses as LS
+from . import train_ops as TO
 
 
 def _p(t):
@@ -109,8 +110,26 @@ class TrainableFF(torch.nn.Module):
     def mlp(self, x, name):                                     # nn.Sequential(Linear, LayerNorm, GELU, Linear)
         w = self.w
         h = lin(x, w[name + ".0.weight"], w[name + ".0.bias"])
-        h = F.layer_norm(h, (h.shape[-1],), w[name + ".1.weight"], w[name + ".1.bias"], 1e-5)
-        return lin(F.gelu(h), w[name + ".3.weight"], w[name + ".3.bias"])
+        h = TO.layer_norm(h, w[name + ".1.weight"], w[name + ".1.bias"], 1e-5, gelu=True)        # LayerNorm + GELU: one kernel each way
+        return lin(h, w[name + ".3.weight"], w[name + ".3.bias"])
+
+    def encoder_packed(self, x, set_off, lens, cls_rows, name):
+        """The same post-LN encoder over PACKED sets (device path): x (T, D) = the sets' tokens back to back, CLS row first; `set_off`
+        (G + 1,) int32 on the device, `lens` (G,) on the host, `cls_rows` (G,) int64 on the device.  Linears on the float32 MFMA GEMM,
+        LayerNorm / GELU / the variable-length set attention on their own forward + backward kernels (train_ops)."""
+        w, H = self.w, self.n_head
+        for i in range(2):
+            p = f"{name}.layers.{i}"
+            last = i == 1
+            qkv = lin(x, w[p + ".self_attn.in_proj_weight"], w[p + ".self_attn.in_proj_bias"])
+            a = TO.set_attention(qkv, set_off, lens, H, q_rows=1 if last else 0)
+            if last:                                            # only the CLS rows feed the output (PRE-FF:966 `[0]`)
+                a, x = a.index_select(0, cls_rows), x.index_select(0, cls_rows)
+            a = lin(a, w[p + ".self_attn.out_proj.weight"], w[p + ".self_attn.out_proj.bias"])
+            x = TO.layer_norm(x + a, w[p + ".norm1.weight"], w[p + ".norm1.bias"], 1e-5)
+            h = lin(TO.gelu(lin(x, w[p + ".linear1.weight"], w[p + ".linear1.bias"])), w[p + ".linear2.weight"], w[p + ".linear2.bias"])
+            x = TO.layer_norm(x + h, w[p + ".norm2.weight"], w[p + ".norm2.bias"], 1e-5)
+        return TO.layer_norm(x, w[name + ".norm.weight"], w[name + ".norm.bias"], 1e-12)
 
     def encoder(self, x, key_mask, name):
         """x (G, L, D), key_mask (G, L) True = real token -> (G, D): post-LN TransformerEncoder x 2 + LayerNorm(1e-12), row 0 (PRE-FF:134-155)."""
@@ -135,6 +154,17 @@ class TrainableFF(torch.nn.Module):
         G, D = len(lens), emb.shape[-1]
         offs = np.concatenate([[0], np.cumsum(lens)])
         T = int(offs[-1])
+        if emb.is_cuda and G > 0:
+            # packed: [CLS; members] of every set back to back, no padding (the layout of the inference path, ff_dense.FFDense.encode_sets)
+            poff = offs + np.arange(G + 1)
+            idx = np.empty(T + G, np.int64)
+            idx[poff[:-1]] = T                                              # row T of `src` is the CLS embedding
+            member = np.ones(T + G, bool)
+            member[poff[:-1]] = False
+            idx[member] = np.arange(T)
+            dev = emb.device
+            x = torch.cat([emb, cls], 0).index_select(0, torch.from_numpy(idx).to(dev))
+            return self.encoder_packed(x, torch.from_numpy(poff.astype(np.int32)).to(dev), lens + 1, torch.from_numpy(poff[:-1].astype(np.int64)).to(dev), enc)
         src = torch.cat([emb, cls, torch.zeros_like(cls)], 0)          # row T = CLS, row T + 1 = padding
         bucket = np.ceil(np.log2(np.maximum(lens, 1) + 1)).astype(np.int64)
         outs, order = [], []
@@ -314,21 +344,41 @@ class FFTrainer:
         return sim + dummy, segm
 
 
-def pretrain_step(ff, trainer: FFTrainer, optimizer, update_kwargs: dict, clip_value: float = 10.0) -> dict:
+def render_target_from_grid(grid: torch.Tensor, hw: int = 24) -> torch.Tensor:
+    """CLIP patch features of the novel view's own image (B, 576, 768) -> the (B, 144, 768) targets of the 12 x 12 ray grid: 2 x 2 average
+    pooling over the 24 x 24 patch grid (PRE-TR:884-888)."""
+    B, _, D = grid.shape
+    g = grid.float().view(B, hw, hw, D).permute(0, 3, 1, 2)
+    return F.avg_pool2d(g, kernel_size=2, stride=2).permute(0, 2, 3, 1).reshape(B, -1, D)
+
+
+def pretrain_step(ff, trainer: FFTrainer, optimizer, update_kwargs: dict, clip_value: float = 10.0, render: Optional[dict] = None) -> dict:
     """One optimisation step (PRE-TR:479-526) on `ff` (a `Feature_Fields(variant="pretrain")`): forward with loss collection, NaN vote over
     the ranks, backward, gradient all-reduce (average), NaN scrub, value clipping, optimizer step; the updated weights are copied into the
-    inference-path modules of `ff`.  Returns {'loss', 'sim_loss', 'segm_loss', 'skipped', 'collectives'}."""
+    inference-path modules of `ff`.  `render` = dict(model=train_render.TrainableRenderer, views=[(positions, headings, target (B, 144, 768)),
+    ...]): novel views rendered differentiably from the memory this step just updated and aligned with the CLIP patch features of their own
+    images (PRE-TR:880-892, 1056-1075); the renderer's parameters must be in `optimizer` too.
+    Returns {'loss', 'sim_loss', 'segm_loss', 'render_loss', 'skipped', 'collectives'}."""
     optimizer.zero_grad(set_to_none=True)
     trainer.begin()
     ff.update_feature_fields(is_training=True, trainer=trainer, **update_kwargs)
     sim, segm = trainer.losses()
     loss = sim if segm is None else sim + segm
-    out = dict(loss=float(loss.detach()), sim_loss=float(sim.detach()), segm_loss=None if segm is None else float(segm.detach()), skipped=False, collectives=0)
+    rl = None
+    if render is not None:
+        preds, tgts = [], []
+        for positions, headings, target in render["views"]:
+            preds.append(render["model"].render(ff, positions, headings))
+            tgts.append(torch.as_tensor(target).to(preds[-1].device, torch.float32))
+        rl = LS.render_loss(torch.cat(preds, 0), torch.cat(tgts, 0))
+        loss = loss + rl
+    out = dict(loss=float(loss.detach()), sim_loss=float(sim.detach()), segm_loss=None if segm is None else float(segm.detach()),
+               render_loss=None if rl is None else float(rl.detach()), skipped=False, collectives=0)
     if DD.any_nan_vote(loss.detach()):                                 # PRE-TR:503-509: a NaN on any rank skips the step on every rank
         out["skipped"] = True
         return out
     loss.backward()
-    params = list(trainer.model.parameters())
+    params = list(trainer.model.parameters()) + (list(render["model"].parameters()) if render is not None else [])
     zero = lambda p: torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()
     trainer.local_grads = {k: zero(p) for k, p in zip(trainer.model.names, trainer.model.plist)}      # this rank's own, raw (kept for the tests)
     # The reference runs backward under DDP (PRE-TR:356-360, 512): gradients are ALREADY averaged over the ranks when it scrubs NaNs
@@ -339,7 +389,20 @@ def pretrain_step(ff, trainer: FFTrainer, optimizer, update_kwargs: dict, clip_v
     trainer.last_grads = {k: zero(p) for k, p in zip(trainer.model.names, trainer.model.plist)}
     optimizer.step()
     sync_weights(ff, trainer.model)
+    if render is not None:
+        sync_render_weights(ff, render["model"])
     return out
+
+
+def sync_render_weights(ff, model):
+    """The inference renderer (`Feature_Fields.render_view_3d_patch`) reads the feature field's own `nerf_*` / `*_to_nerf_*` parameters:
+    copy the trained tensors into them (in place) and let the renderer be rebuilt from them on its next use."""
+    own = dict(ff.named_parameters())
+    with torch.no_grad():
+        for k, v in model.layer_weights().items():
+            if k in own:
+                own[k].copy_(v.to(own[k].device, own[k].dtype))
+    ff._renderer = None
 
 
 def sync_weights(ff, model: TrainableFF):

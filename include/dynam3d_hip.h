@@ -294,6 +294,27 @@ int32_t d3d_transpose_pad16(const void* in_d /* (R,C), row stride ld_in */, void
                             int64_t ld_in, int32_t Rp /* % 64, >= R */, void* stream);
 /* dz = dy * (y > 0 ? 1 : 0.01) over n 16-bit elements (n % 8 == 0): LeakyReLU(0.01) backward from the layer's OUTPUT y */
 int32_t d3d_lrelu_bwd(const void* dy_d, const void* y_d, void* dz_d, int64_t n, int32_t dtype, void* stream);
+/* ---- backward of the float32 token-builder modules and of the compositing (the pre-training step's gradients through
+ * a7 / a11 / a22 / a23 on the device; replaces PyTorch autograd expressions, PRE-FF:134-161, 446-474) ----
+ * d3d_layer_norm_bwd_f32: y = [gelu](LayerNorm(x) * w + b) (nn.LayerNorm [+ nn.GELU], the forward of d3d_layer_norm_f32 without residual).
+ *   dx (rows, D); dw_part / db_part (ceil(rows / d3d_layer_norm_bwd_rows_per_block()), D): per-workgroup column sums of dz * xhat / dz,
+ *   written in full (no zero-initialisation needed), summed over the first axis by the caller -- a fixed order, hence deterministic. */
+int32_t d3d_layer_norm_bwd_f32(const float* x_d, const float* w_d, const float* b_d, const float* dy_d, float* dx_d, float* dw_part_d,
+                               float* db_part_d, int32_t rows, int32_t D, int64_t ldx, int64_t lddy, int64_t lddx, float eps, int32_t gelu,
+                               void* stream);
+int32_t d3d_layer_norm_bwd_rows_per_block(void);
+/* exact (erf) GELU on float32: dy_d == NULL: out = gelu(z); else out = dy * gelu'(z) (the backward of the same op). */
+int32_t d3d_gelu_f32(const float* z_d, const float* dy_d, float* out_d, int64_t n, void* stream);
+/* d3d_set_attention_bwd: gradient of d3d_set_attention (same qkv / set_off / q_rows).  out = the forward's result, dout = dL/dout (rows
+ * that were not queried are ignored); dqkv (T, 3*H*64): the k / v thirds are written for every row, the q third for the QUERIED rows
+ * only (zero-fill dqkv when q_rows > 0); lse_scratch / d_scratch (T, H) float32 each. */
+int32_t d3d_set_attention_bwd(const float* qkv_d, const float* out_d, const float* dout_d, const int32_t* set_off_d, int32_t n_sets, int32_t n_heads,
+                              int32_t max_len, int32_t q_rows, float* dqkv_d, float* lse_scratch_d, float* d_scratch_d, void* stream);
+/* d3d_composite_bwd: gradient of d3d_composite's feature map w.r.t. the 16-bit sample features / densities it read (same arguments);
+ * gout (n_rays, 768) = dL/d(feature map); dfeat (n_rays * n_imp, 768) and ddens (n_rays * n_imp) float32.  (The expected depth is not
+ * differentiated: the reference's losses do not use it, PRE-TR:1056-1075.) */
+int32_t d3d_composite_bwd(const void* feat16_d, int64_t ldf, const void* dens16_d, int64_t ldd, const float* rel_dist_d, const int32_t* topk_d,
+                          const float* gout_d, int32_t n_rays, int32_t N, int32_t n_imp, float* dfeat_d, float* ddens_d, void* stream);
 
 /* One KV-cache decode token through the whole Phi-3 stack (HF Phi3DecoderLayer x n_layers + final norm + lm_head under
  * `llava.generate`, VLN-POL:463), every launch issued from C++.  All pointers are device pointers except the per-layer pointer

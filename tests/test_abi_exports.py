@@ -26,7 +26,7 @@ def test_library_exports_all_declared_symbols():
 
 def test_signature_table_covers_kernel_entry_points():
     syms = set(declared_symbols())
-    from dynam3d_amd import f32_ops, hip_dense, render, segm, tcnn  # noqa: F401  (register the dense / float32 / renderer / segmenter / training signatures)
+    from dynam3d_amd import f32_ops, hip_dense, render, segm, tcnn, train_ops  # noqa: F401  (register the dense / float32 / renderer / segmenter / training signatures)
     bound = set(_lib.SIGNATURES) | set(_lib.FFSTATE_SYMBOLS) | set(_lib.MISC_SYMBOLS) | {"d3d_ff_set_tomb_cell"}
     assert syms <= bound | {"d3d_ff_set_tomb_cell"}, sorted(syms - bound)
 

@@ -82,6 +82,7 @@ def test_closed_loop_rollout_full_model_8x50():
     cfg = PolicyConfig()
     D.enable_hip_kernels(["all"])
     D.strict(True)
+    D.reset_counts()
     try:
         net = Dynam3D_VLN(cfg, synth_policy_weights(cfg, 0, device="cuda"), device="cuda", batch_size=8, max_steps=51,
                           tokenizer=ActionGrammarTokenizer(cfg.llm.vocab, stop_mod=40))
@@ -93,7 +94,8 @@ def test_closed_loop_rollout_full_model_8x50():
     finally:
         D.strict(False)
     kinds = {("stop" if a is None else "move") for t in trace for a in t["actions"]}
-    lens = sorted(int(s) for s in np.bincount([i for t in trace for i in range(len(t["texts"]))]))
+    alive = [len(t["texts"]) for t in trace] + [0]
+    lens = sorted(k + 1 for k in range(len(trace)) for _ in range(alive[k] - alive[k + 1]))          # episode k ended after its step k
     print(f"closed loop 8 x 50: {int(sums['steps_taken'])} env steps in {dt:.2f} s = {sums['steps_taken'] / dt:.1f} env-steps/s incl. 20-token generation; "
           f"episode lengths {lens}; actions seen {sorted(kinds)}; mean path {sums['path_length'] / 8:.2f} m")
     assert sums["steps_taken"] >= 8 and not D.counts()["fallback"]
