@@ -1,4 +1,4 @@
-"""Target of the round-3 --pmc passes over the v2 flash-attention kernel: the step's own packed causal Phi-3 shape / the ViT towers' shape."""
+"""Target of the --pmc passes over the flash-attention kernel (tools/profile_round.sh): the step's own packed causal Phi-3 shape / the ViT towers' shape."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,12 +1,13 @@
 #!/bin/bash
-# Round-3 profile set -> gpurun_out/r03/ (copy the summaries into profiles/):
+# Per-round profile set: `bash tools/profile_round.sh r04` -> gpurun_out/r04/ (copy the summaries into profiles/ with the round prefix):
 #   1. rocprofv3 kernel trace + stats of the DEFAULT benchmark command; per-kernel summary; one row per timed gate_up launch
 #   2. three --pmc passes over the dominant GEMM (gate_up, M = 6656: the mean packed rows of the timed steps)
-#   3. --pmc passes over the v2 flash-attention kernel at the Phi-3 packed shape and the ViT shape (VALU vs MFMA busy)
+#   3. --pmc passes over the flash-attention kernel at the Phi-3 packed shape and the ViT shape (VALU vs MFMA busy)
 #   4. kernel trace of the Pretrain render path (tools/bench_render.py)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/r03
+round=${1:-r04}
+out=gpurun_out/$round
 rm -rf $out && mkdir -p $out
 # ---- 1. benchmark trace ----------------------------------------------------------------------------------------------------------
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python bench.py --cpu-baseline off > $out/bench_prof.json 2> $out/bench_prof.err
@@ -33,7 +34,7 @@ for shape in phi3 vit; do
              "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE" \
              "FETCH_SIZE"; do
     i=$((i+1))
-    timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/a$i -- python tools/attn_pmc_r03.py $shape > $out/a$i.log 2>&1
+    timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/a$i -- python tools/attn_pmc.py $shape > $out/a$i.log 2>&1
     f=$(find $out/a$i -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && cp "$f" $out/attn_${shape}_p${i}_counters.csv
     rm -rf $out/a$i
