@@ -22,11 +22,13 @@ extern "C" int32_t d3d_phi3_decode_token(const d3d_phi3_decode_args* a) {
         return D3D_EINVAL;
     }
     if (d3d_phi3_decode_persistent_ok(a)) return d3d_phi3_decode_token_persistent(a);      // (D3D_DECODE_PERSISTENT=0: the launch-per-op path below)
-    // D3D_DECODE_FUSE_NORM=1: RMSNorm inside the projection that follows it (d3d_gemm_nt_rmsnorm: 5 launches per layer instead of 7).
-    // Bit-identical, but SLOWER -- 3.76 against 3.46 ms per token (tools/bench_decode.py): every workgroup of the GEMM re-reads the 8 rows
-    // and normalises its fragments in the loop that should only be waiting for weights, which costs more than the 7 us launch it saves.
+    // RMSNorm inside the projection that follows it (d3d_gemm_nt_rmsnorm: 5 launches per layer instead of 7), bit-identical to norm + GEMM.
+    // History (tools/bench_decode.py, ms per token against 3.46-3.50 unfused): normalising every activation fragment inside the K loop 3.76
+    // (round 2); the rows normalised once per workgroup into LDS 3.67 (the extra 49 KB pushed the 16-wave workgroups to one per CU);
+    // with that buffer overlaid on the wave-reduction buffer (two per CU again) 3.38 -- the default since round 4.  D3D_DECODE_FUSE_NORM=0
+    // selects the seven-launch layer.
     const char* fe = getenv("D3D_DECODE_FUSE_NORM");
-    const bool fuse = fe && fe[0] == '1' && Hd % 512 == 0 && qkv_w % 32 == 0 && (2 * I) % 32 == 0;
+    const bool fuse = !(fe && fe[0] == '0') && Hd % 512 == 0 && qkv_w % 32 == 0 && (2 * I) % 32 == 0;
     void* s = a->stream;
     void* x = a->x;                       // (rows, hidden) in / out: the residual stream
     int32_t rc;

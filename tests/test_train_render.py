@@ -112,7 +112,7 @@ def test_pretrain_step_with_render_loss_on_hip():
     own = dict(ff.named_parameters())
     for k, v in after.items():
         assert torch.equal(own[k].detach(), v.to(own[k].dtype)), k
-    feats, _pos, _ = ff.render_view_3d_patch(inp["positions"], inp["headings"])                 # inference renderer rebuilt from the trained weights
+    feats = ff.render_view_3d_patch(inp["positions"], inp["headings"])[0]                       # inference renderer rebuilt from the trained weights
     with torch.no_grad():
         fm = rmodel.render(ff, inp["positions"], inp["headings"])
     r = float((feats.view(fm.shape) - fm).norm() / fm.norm())
