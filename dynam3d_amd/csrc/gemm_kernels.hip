@@ -218,15 +218,11 @@ constexpr int TM = 256, TN = 256, T_THREADS = 512;
 // that would not fill a round, each cut into `splits` K-slices so that the partial last round lasts 1/splits of a tile
 // instead of a whole one.  Every slice writes its fp32 accumulators to the workspace and leaves; k_splitk_fixup (the next launch)
 // sums the slices in slice order -- deterministic -- and runs the fused epilogue.
-// TNT: tile width.  256 = the square tile.  128 = a 256 x 128 tile (round 4; interleaved loop only): wave tile 128 x 32, 16 MFMAs and 10
-// fragment reads per K-half, 96 KiB of LDS -- for the GEMMs whose N is too small for a grid of square tiles (ViT out-proj / fc2, N = 1024:
-// 4 x 19 = 76 square tiles for 256 CUs) and whose 128 x 64 tiles (592 workgroups, three per CU) are bound by the L2 -> LDS rate instead
-// (42.7 FLOP per staged byte; this tile: 85).
-template <bool BF16, int EPI, bool KFULL, bool SPLIT, int DMAV = 0, int TNT = 256>
+template <bool BF16, int EPI, bool KFULL, bool SPLIT, int DMAV = 0>
 __global__ void __launch_bounds__(T_THREADS, 2)
 k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* __restrict__ C,
               const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, int M, int N, int K, int64_t lda,
-              int64_t ldw, int64_t ldc, int tiles_m, int tiles_n, int dp_tiles, int splits, float* __restrict__ ws, int ws_plain = 0) {
+              int64_t ldw, int64_t ldc, int tiles_m, int tiles_n, int dp_tiles, int splits, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [2][A 256x64 | B 256x64]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = K / BK;
@@ -264,31 +260,28 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     const int gsz = min(GM, tiles_m - gm0);
     const int tm = gm0 + (wg % (GM * tiles_n)) % gsz;
     const int tn = (wg % (GM * tiles_n)) / gsz;
-    static_assert(TNT == 256 || (TNT == 128 && (DMAV & 15) == 2 && !SPLIT), "the 256 x 128 tile exists for the unsplit interleaved loop");
-    const int row0 = tm * TM, col0 = tn * TNT;
+    const int row0 = tm * TM, col0 = tn * TN;
 
     const int grp = wave >> 2;                 // wave group == M half of the tile; waves w and w+4 share a SIMD
     const int wn = wave & 3;
     const int fi = lane & 15, fg = lane >> 4;
-    constexpr int NJ = TNT / 64;               // 16-column MFMA tiles per wave: the wave covers columns [wn * TNT / 4, +TNT / 4)
-    constexpr int WCOL = TNT / 4;
-    constexpr int BUF = (TM + TNT) * BK;       // elements per K-tile buffer (A then B)
+    constexpr int BUF = 2 * TM * BK;           // elements per K-tile buffer (A then B)
 
-    float4v acc[8][NJ];
+    float4v acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
     constexpr int NH = KFULL ? 2 : 1;          // K-halves held in registers per step
-    uint4 af[NH][8], bf[NH][NJ];
+    uint4 af[NH][8], bf[NH][4];
 
     // LOAD(t, kk): the 12 fragments of K-half kk (32 deep) of tile t -> 48 VGPRs
     auto LOAD = [&](int t, int kk, int slot) {
         const uint16_t* la = smem + ((t - kb) & 1) * BUF;
         const uint16_t* lb = la + TM * BK;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int rb = wn * WCOL + j * 16 + fi;
+        for (int j = 0; j < 4; ++j) {
+            const int rb = wn * 64 + j * 16 + fi;
             bf[slot][j] = *reinterpret_cast<const uint4*>(lb + rb * BK + (((kk * 4 + fg) ^ (rb & 7)) << 3));
         }
 #pragma unroll
@@ -301,7 +294,7 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16<BF16>(bf[slot][j], af[slot][i], acc[i][j]);
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<BF16>(bf[slot][j], af[slot][i], acc[i][j]);
     };
 
     const uint32_t lds0 = lds_addr_of(smem);
@@ -310,12 +303,8 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
     tw.init(ldw, col0, N, wave, lane);
     const uint16_t* abase = A + (int64_t)row0 * lda;
     const uint16_t* wbase = W + (int64_t)col0 * ldw;
-    auto STAGE_W = [&](const uint16_t* src, uint32_t dst) {           // the W tile: TNT rows = TNT / 64 pieces per wave
-        if constexpr (TNT == 256) stage_tile_dma<8>(tw, src, dst, wave);
-        else stage_tile_dma2<8>(tw, src, dst, wave);
-    };
     stage_tile_dma<8>(ta, abase + kb * BK, lds0, wave);
-    STAGE_W(wbase + kb * BK, lds0 + TM * BK * 2);
+    stage_tile_dma<8>(tw, wbase + kb * BK, lds0 + TM * BK * 2, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -342,33 +331,29 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
                          const uint16_t* wsrc, const uint32_t dst) {
             const int ns = cs ^ 1;
             const uint16_t* lb = la + TM * BK;
-            constexpr int NMF = 8 * NJ, NRD = 8 + NJ, NPC = 4 + NJ;    // MFMAs, fragment reads, LDS-DMA pieces of a phase (32 / 12 / 8 for the square tile)
 #pragma unroll
-            for (int m = 0; m < NMF; ++m) {
-                const int i = m / NJ, j = m % NJ;
+            for (int m = 0; m < 32; ++m) {
+                const int i = m >> 2, j = m & 3;
                 acc[i][j] = mfma16<BF16>(bf[cs][j], af[cs][i], acc[i][j]);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (rd) {
 #pragma unroll
-                    for (int r = 0; r < NRD; ++r) {
-                        if ((r * NMF) / NRD != m) continue;            // the reads spread evenly behind the MFMAs (square tile: one behind every ~3rd)
-                        if (r < NJ) {
-                            const int rb = wn * WCOL + r * 16 + fi;
+                    for (int r = 0; r < 12; ++r) {
+                        if ((r * 8) / 3 != m) continue;
+                        if (r < 4) {
+                            const int rb = wn * 64 + r * 16 + fi;
                             bf[ns][r] = *reinterpret_cast<const uint4*>(lb + rb * BK + (((kk * 4 + fg) ^ (rb & 7)) << 3));
                         } else {
-                            const int ra = grp * 128 + (r - NJ) * 16 + fi;
-                            af[ns][r - NJ] = *reinterpret_cast<const uint4*>(la + ra * BK + (((kk * 4 + fg) ^ (ra & 7)) << 3));
+                            const int ra = grp * 128 + (r - 4) * 16 + fi;
+                            af[ns][r - 4] = *reinterpret_cast<const uint4*>(la + ra * BK + (((kk * 4 + fg) ^ (ra & 7)) << 3));
                         }
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 }
-                if (dma) {
-#pragma unroll
-                    for (int p = 0; p < NPC; ++p) {
-                        if ((TNT == 256 ? p * 3 : (p * NMF) / NPC) + 1 != m) continue;   // pieces 0-3: A, the rest: W (square tile: behind MFMAs 1, 4, ... 22)
-                        if (p < 4) stage_piece_dma(ta.off[p], asrc, dst + (uint32_t)p * 8192u);
-                        else stage_piece_dma(tw.off[p - 4], wsrc, dst + TM * BK * 2 + (uint32_t)(p - 4) * 8192u);
-                    }
+                if (dma && m % 3 == 1 && m / 3 < 8) {
+                    const int p = m / 3;                       // pieces 0-3: A, 4-7: W
+                    if (p < 4) stage_piece_dma(ta.off[p], asrc, dst + (uint32_t)p * 8192u);
+                    else stage_piece_dma(tw.off[p - 4], wsrc, dst + TM * BK * 2 + (uint32_t)(p - 4) * 8192u);
                 }
             }
         };
@@ -385,7 +370,7 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
         };
         if (kb + 1 < ke) {
             stage_tile_dma<8>(ta, abase + (kb + 1) * BK, lds0 + BUF * 2, wave);
-            STAGE_W(wbase + (kb + 1) * BK, lds0 + BUF * 2 + TM * BK * 2);
+            stage_tile_dma<8>(tw, wbase + (kb + 1) * BK, lds0 + BUF * 2 + TM * BK * 2, wave);
         }
         LOAD(kb, 0, 0);
         int t = kb;
@@ -482,10 +467,7 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (ws_plain) slot[(i * 4 + j) * T_THREADS] = acc[i][j];       // (D3D_SPLITK_PLAIN=1: partial sums through the caches)
-                    else __builtin_nontemporal_store(acc[i][j], slot + (i * 4 + j) * T_THREADS);
-                }
+                for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[i][j], slot + (i * 4 + j) * T_THREADS);
             return;
         }
     }
@@ -496,12 +478,12 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
             const int m = row0 + grp * 128 + i * 16 + fi;
             if (m >= M) continue;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) store4<BF16, EPI>(acc[i][j], acc[i][j], C, bias, residual, m, col0 + wn * WCOL + j * 16, fg, ldc);
+            for (int j = 0; j < 4; ++j) store4<BF16, EPI>(acc[i][j], acc[i][j], C, bias, residual, m, col0 + wn * 64 + j * 16, fg, ldc);
         }
     } else {
         __builtin_amdgcn_s_barrier();              // every wave is done reading the K-tile buffers
-        epilogue_transposed<BF16, EPI, 8, NJ>(acc, reinterpret_cast<char*>(smem) + wave * (128 * (EPI == EPI_SWIGLU ? 16 : 32) * NJ), lane,
-                                              row0 + grp * 128, col0 + wn * WCOL, M, C, bias, residual, ldc);
+        epilogue_transposed<BF16, EPI, 8>(acc, reinterpret_cast<char*>(smem) + wave * (128 * (EPI == EPI_SWIGLU ? 64 : 128)), lane,
+                                          row0 + grp * 128, col0 + wn * 64, M, C, bias, residual, ldc);
     }
     if constexpr (TIMED) {
         tk[3] = __builtin_readcyclecounter();
@@ -520,12 +502,6 @@ inline bool gemm_loop_interleaved() {
     return v;
 }
 
-// D3D_SPLITK_PLAIN=1: the split-K partial sums are written / read with ordinary (cached) accesses instead of non-temporal ones (A/B knob)
-inline int splitk_plain() {
-    const char* e = getenv("D3D_SPLITK_PLAIN");       // read per call: the benchmarks toggle it inside one process
-    return e && e[0] == '1' ? 1 : 0;
-}
-
 inline int tile_group_m() {
     static const int gm = [] {
         const char* e = getenv("D3D_GEMM_GM");
@@ -535,20 +511,20 @@ inline int tile_group_m() {
     return gm;
 }
 
-template <bool BF16, int EPI, bool KFULL, int DMAV = 0, int TNT = 256>
+template <bool BF16, int EPI, bool KFULL, int DMAV = 0>
 int32_t launch256(const void* A, const void* W, void* C, const void* bias, const void* res, int M, int N, int K, int64_t lda,
                   int64_t ldw, int64_t ldc, hipStream_t s) {
-    const int tm = (M + TM - 1) / TM, tn = N / TNT;
-    const size_t sh = 2 * (TM + TNT) * BK * sizeof(uint16_t);   // 128 KiB (96 KiB for the 256 x 128 tile)
+    const int tm = (M + TM - 1) / TM, tn = N / TN;
+    const size_t sh = 2 * 2 * TM * BK * sizeof(uint16_t);   // 128 KiB
     static std::once_flag attr_once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(attr_once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, KFULL, false, DMAV, TNT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, KFULL, false, DMAV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     });
     D3D_HIP(attr_err);
     float* dbg = nullptr;
     if constexpr ((DMAV & 16) != 0) D3D_HIP(hipMalloc(&dbg, (size_t)tm * tn * 6 * sizeof(unsigned long long)));
-    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL, false, DMAV, TNT>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W,
+    hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL, false, DMAV>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W,
                        (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, tile_group_m(), dbg);
     if constexpr ((DMAV & 16) != 0) {
         // diagnostics: per-workgroup cycle stamps -> one line on stderr (mean over workgroups)
@@ -574,7 +550,7 @@ int32_t launch256(const void* A, const void* W, void* C, const void* bias, const
 template <bool BF16, int EPI>
 __global__ void __launch_bounds__(T_THREADS)
 k_splitk_fixup(const float* __restrict__ ws, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual,
-               int M, int64_t ldc, int tiles_m, int tiles_n, int dp_tiles, int splits, int ws_plain) {
+               int M, int64_t ldc, int tiles_m, int tiles_n, int dp_tiles, int splits) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tail_idx = blockIdx.x >> 3, i = blockIdx.x & 7;
     const int wg = dp_tiles + tail_idx;
@@ -589,12 +565,12 @@ k_splitk_fixup(const float* __restrict__ ws, uint16_t* __restrict__ C, const uin
     const float4v* base = reinterpret_cast<const float4v*>(ws) + (int64_t)tail_idx * splits * (32 * T_THREADS) + (i * 4) * T_THREADS + tid;
     float4v sum[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sum[j] = ws_plain ? base[j * T_THREADS] : __builtin_nontemporal_load(base + j * T_THREADS);
+    for (int j = 0; j < 4; ++j) sum[j] = __builtin_nontemporal_load(base + j * T_THREADS);
     for (int sl = 1; sl < splits; ++sl) {
         const float4v* p = base + (int64_t)sl * (32 * T_THREADS);
         float4v v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = ws_plain ? p[j * T_THREADS] : __builtin_nontemporal_load(p + j * T_THREADS);
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_nontemporal_load(p + j * T_THREADS);
 #pragma unroll
         for (int j = 0; j < 4; ++j) sum[j] += v[j];
     }
@@ -680,9 +656,9 @@ int32_t launch256_split(const void* A, const void* W, void* C, const void* bias,
     D3D_HIP(attr_err);
     hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, true, true, DMAV>), dim3(dp_tiles + tail * splits), dim3(T_THREADS), sh, s, (const uint16_t*)A,
                        (const uint16_t*)W, (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, dp_tiles,
-                       splits, w->ws, splitk_plain());
+                       splits, w->ws);
     hipLaunchKernelGGL((k_splitk_fixup<BF16, EPI>), dim3(tail * 8), dim3(T_THREADS), 0, s, (const float*)w->ws, (uint16_t*)C, (const uint16_t*)bias,
-                       (const uint16_t*)res, M, ldc, tm, tn, dp_tiles, splits, splitk_plain());
+                       (const uint16_t*)res, M, ldc, tm, tn, dp_tiles, splits);
     D3D_LAUNCH_CHECK();
 }
 
@@ -1014,28 +990,6 @@ int32_t d3d_gemm_nt_tile(const void* A, const void* W, void* C, const void* bias
                          int64_t lda, int64_t ldw, int64_t ldc, int32_t dtype, int32_t epilogue, int32_t tile, void* stream) {
     if (M <= 0) return D3D_OK;
     if (tile == 16) return skinny_dispatch(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, dtype, epilogue, stream);
-    if (tile == 266) {                       // 256 x 128 tile, interleaved loop (the epilogues the ViT / Phi-3 linears with a narrow N carry)
-        if (N % 128 != 0 || K % BK != 0 || (lda & 7) || (ldw & 7) || (ldc & 7) || ((uintptr_t)C & 15) || (residual && ((uintptr_t)residual & 15))) {
-            d3d_set_error_("d3d_gemm_nt_tile 266: needs N % 128 == 0, K % 64 == 0, lda / ldw / ldc % 8 == 0, 16-byte aligned C / residual");
-            return D3D_EINVAL;
-        }
-        hipStream_t s6 = (hipStream_t)stream;
-#define D3D_G266(E)                                                                                                                  \
-    case E:                                                                                                                          \
-        return dtype == 0 ? launch256<true, E, true, 2, 128>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s6)                     \
-                          : launch256<false, E, true, 2, 128>(A, W, C, bias, residual, M, N, K, lda, ldw, ldc, s6);
-        switch (epilogue) {
-            D3D_G266(EPI_NONE)
-            D3D_G266(EPI_BIAS)
-            D3D_G266(EPI_BIAS_QGELU)
-            D3D_G266(EPI_BIAS_GELU)
-            D3D_G266(EPI_RES)
-            D3D_G266(EPI_BIAS_RES)
-        }
-#undef D3D_G266
-        d3d_set_error_("d3d_gemm_nt_tile 266: epilogues none / bias / bias + QuickGELU / bias + GELU / residual / bias + residual");
-        return D3D_EINVAL;
-    }
     if (tile != 128 && tile != 130 && tile != 132 && tile != 164 && (tile < 256 || (tile > 264 && (tile < 301 || tile > 303)))) {
         d3d_set_error_("d3d_gemm_nt_tile: tile must be 128 (130 / 132: 2 / 4 LDS stages forced), 256 (K-half steps), 257 (whole-K-tile steps) or 258 (257 + split-K tail)");
         return D3D_EINVAL;

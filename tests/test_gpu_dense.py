@@ -101,31 +101,6 @@ def test_gemm_forced_tile_kernels(hd, dt, tol, tile):
         HipDense.TILE = 0
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1e-3), (torch.float16, 2e-4)])
-def test_gemm_256x128_tile(hd, dt, tol):
-    """Tile code 266: the 256 x 128 tile of the interleaved kernel (narrow-N linears: ViT out-proj / fc2).  Ragged M, one / many K tiles,
-    N = 128 (one column tile) ... 1024, the epilogues it is built for; equal to the 128-tile kernel's results up to float32 summation order."""
-    from dynam3d_amd import _lib
-    from dynam3d_amd.hip_dense import EPI, _p
-    torch.manual_seed(7)
-    for M, N, K in ((300, 128, 64), (512, 384, 128), (4616, 1024, 1024), (4616, 1024, 4096), (1000, 640, 192)):
-        x = (torch.randn(M, K, device="cuda") * 0.7).to(dt)
-        w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
-        w[3] *= 4.0
-        b = (torch.randn(N, device="cuda") * 0.3).to(dt)
-        r = torch.randn(M, N, device="cuda").to(dt)
-        y32 = x.float() @ w.float().t()
-        for epi, bias, res in (("none", None, None), ("bias", b, None), ("res", None, r), ("bias_res", b, r)):
-            out = torch.empty((M, N), dtype=dt, device="cuda")
-            _lib.check(hd.lib.d3d_gemm_nt_tile(_p(x), _p(w), _p(out), _p(bias), _p(res), M, N, K, x.stride(0), w.stride(0), N, 0 if dt == torch.bfloat16 else 1,
-                                               EPI[epi], 266, hd._stream()))
-            assert rel(out.float(), epi_ref(epi, y32, bias, res, dt)) < tol, (M, N, K, epi, rel(out.float(), epi_ref(epi, y32, bias, res, dt)))
-            again = torch.empty_like(out)
-            _lib.check(hd.lib.d3d_gemm_nt_tile(_p(x), _p(w), _p(again), _p(bias), _p(res), M, N, K, x.stride(0), w.stride(0), N, 0 if dt == torch.bfloat16 else 1,
-                                               EPI[epi], 266, hd._stream()))
-            assert torch.equal(out, again)
-
-
 @pytest.mark.parametrize("tile", [258, 264])
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1e-3), (torch.float16, 2e-4)])
 def test_gemm_split_k_tail(hd, dt, tol, tile):

@@ -36,7 +36,7 @@ def gemm(x, w, out, bias, res, epi, tile):
         _lib.check(hd.lib.d3d_gemm_nt_tile(_p(x), _p(w), _p(out), _p(bias), _p(res), M, N, K, x.stride(0), w.stride(0), N, dt, EPI[epi], tile, hd._stream()))
 
 
-TILES = (0, 130, 164, 260, 264, 266)
+TILES = (0, 130, 132, 164, 260, 264)
 Ms = [int(m) for m in os.environ.get("SWEEP_M", "4616,4608").split(",")]
 for dtype in (torch.float16,):
     for M in Ms:
