@@ -486,6 +486,139 @@ k_knn(const float* __restrict__ points, int64_t point_stride, const int32_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// a21 radius-limited KNN (the novel-view renderer, PRE-FF:540-566: neighbours at >= 1 m are discarded right behind the query, so only
+// neighbours INSIDE the radius have to be exact).  Same thread-per-query top-k as k_knn, but a workgroup first boxes its 256 queries
+// (consecutive depth samples of one ray: a thin 5 m segment) and, tile by tile, compacts the points that lie inside the box grown by the
+// radius into LDS -- in index order, so ties still go to the lower index -- and only those are scored.  A point outside the grown box is
+// farther than `radius` from every query of the workgroup.  Every neighbour with d^2 < radius^2 comes out exactly as k_knn reports it
+// (same d^2 expression, same order); slots beyond the radius hold either a farther point or (inf, -1).
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(KNN_BLOCK)
+k_knn_radius(const float* __restrict__ points, int64_t point_stride, const int32_t* __restrict__ n_points,
+             const float* __restrict__ queries, int64_t query_stride, const int32_t* __restrict__ n_queries,
+             const int32_t* __restrict__ kk, int max_queries, float radius, float* __restrict__ d2_out, int32_t* __restrict__ idx_out) {
+    __shared__ float tile[KNN_TILE * 3];
+    __shared__ int tidx[KNN_TILE];
+    __shared__ float box[6][KNN_BLOCK / WAVE];
+    __shared__ int wcount[KNN_TILE / WAVE];
+    const int b = blockIdx.y;
+    const int nq = n_queries[b], np = n_points[b];
+    if ((int)(blockIdx.x * KNN_BLOCK) >= nq) return;
+    const int k = kk[b];
+    const int q = blockIdx.x * KNN_BLOCK + threadIdx.x;
+    const bool active = q < nq;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const float* P = points + (size_t)b * point_stride;
+    float qx = 0, qy = 0, qz = 0;
+    if (active) {
+        const float* Q = queries + (size_t)b * query_stride + (size_t)q * 3;
+        qx = Q[0];
+        qy = Q[1];
+        qz = Q[2];
+    }
+    // bounding box of the workgroup's queries
+    float lo[3] = {active ? qx : INFINITY, active ? qy : INFINITY, active ? qz : INFINITY};
+    float hi[3] = {active ? qx : -INFINITY, active ? qy : -INFINITY, active ? qz : -INFINITY};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+        }
+        if (lane == 0) {
+            box[a][wave] = lo[a];
+            box[3 + a][wave] = hi[a];
+        }
+    }
+    __syncthreads();
+    const float grow = radius * 1.0001f + 1e-4f;          // conservative: rounding of the box arithmetic never drops a point inside the radius
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = fminf(fminf(box[a][0], box[a][1]), fminf(box[a][2], box[a][3])) - grow;
+        hi[a] = fmaxf(fmaxf(box[3 + a][0], box[3 + a][1]), fmaxf(box[3 + a][2], box[3 + a][3])) + grow;
+    }
+    float bd[K];
+    int bi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        bd[j] = INFINITY;
+        bi[j] = -1;
+    }
+    for (int t0 = 0; t0 < np; t0 += KNN_TILE) {
+        const int cnt = min(KNN_TILE, np - t0);
+        // ---- compaction of the tile's points that fall into the grown box, in index order: point i = j * 256 + thread ----
+        float px[KNN_TILE / KNN_BLOCK], py[KNN_TILE / KNN_BLOCK], pz[KNN_TILE / KNN_BLOCK];
+        unsigned long long bal[KNN_TILE / KNN_BLOCK];
+        __syncthreads();                                    // the previous tile's list is no longer read
+#pragma unroll
+        for (int j = 0; j < KNN_TILE / KNN_BLOCK; ++j) {
+            const int i = j * KNN_BLOCK + threadIdx.x;
+            bool in = false;
+            if (i < cnt) {
+                const float* pp = P + (size_t)(t0 + i) * 3;
+                px[j] = pp[0];
+                py[j] = pp[1];
+                pz[j] = pp[2];
+                in = px[j] >= lo[0] && px[j] <= hi[0] && py[j] >= lo[1] && py[j] <= hi[1] && pz[j] >= lo[2] && pz[j] <= hi[2];
+            }
+            bal[j] = __ballot(in);
+            if (lane == 0) wcount[j * (KNN_BLOCK / WAVE) + wave] = __popcll(bal[j]);
+        }
+        __syncthreads();
+        int n_in = 0;
+#pragma unroll
+        for (int j = 0; j < KNN_TILE / KNN_BLOCK; ++j) {
+            int base = 0;
+            for (int w = 0; w < j * (KNN_BLOCK / WAVE) + wave; ++w) base += wcount[w];
+            if ((bal[j] >> lane) & 1ull) {
+                const int o = base + __popcll(bal[j] & ((1ull << lane) - 1ull));
+                tile[o * 3] = px[j];
+                tile[o * 3 + 1] = py[j];
+                tile[o * 3 + 2] = pz[j];
+                tidx[o] = t0 + j * KNN_BLOCK + threadIdx.x;
+            }
+        }
+        for (int w = 0; w < KNN_TILE / WAVE; ++w) n_in += wcount[w];
+        __syncthreads();
+        if (active) {
+            for (int i = 0; i < n_in; ++i) {
+                const float dx = qx - tile[i * 3], dy = qy - tile[i * 3 + 1], dz = qz - tile[i * 3 + 2];
+                const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                const float s = xx + yy;
+                const float d = s + zz;
+                if (d < bd[K - 1]) {  // strict: equal distances keep the earlier (lower) index
+                    bd[K - 1] = d;
+                    bi[K - 1] = tidx[i];
+#pragma unroll
+                    for (int j = K - 1; j > 0; --j) {
+                        if (bd[j] < bd[j - 1]) {
+                            const float td = bd[j];
+                            bd[j] = bd[j - 1];
+                            bd[j - 1] = td;
+                            const int ti = bi[j];
+                            bi[j] = bi[j - 1];
+                            bi[j - 1] = ti;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (active) {
+        const size_t o = ((size_t)b * max_queries + q) * K;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (j < k) {
+                d2_out[o + j] = bd[j];
+                idx_out[o + j] = bi[j];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // a7/a10 group statistics (7-vector); one block per group, members staged through LDS in chunks,
 // centroid = sequential float64 sum (deterministic, == oracle mean_rows_f64)
 // ------------------------------------------------------------------------------------------------
@@ -879,6 +1012,33 @@ int32_t d3d_knn(const float* points, int64_t point_stride, const int32_t* n_poin
             return D3D_EINVAL;
     }
 #undef D3D_KNN_CASE
+    D3D_LAUNCH_CHECK();
+}
+
+int32_t d3d_knn_radius(const float* points, int64_t point_stride, const int32_t* n_points, const float* queries, int64_t query_stride,
+                       const int32_t* n_queries, const int32_t* k, int32_t n_batch, int32_t max_queries, int32_t k_max, float radius, float* d2,
+                       int32_t* idx, void* stream) {
+    if (n_batch <= 0 || max_queries <= 0) return D3D_OK;
+    if (!(radius > 0.f)) {
+        d3d_set_error_("d3d_knn_radius: radius must be positive");
+        return D3D_EINVAL;
+    }
+    dim3 grid((max_queries + KNN_BLOCK - 1) / KNN_BLOCK, n_batch);
+#define D3D_KNNR_CASE(KK)                                                                                                         \
+    case KK:                                                                                                                      \
+        hipLaunchKernelGGL(k_knn_radius<KK>, grid, dim3(KNN_BLOCK), 0, (hipStream_t)stream, points, point_stride, n_points, queries, \
+                           query_stride, n_queries, k, max_queries, radius, d2, idx);                                             \
+        break;
+    switch (k_max) {
+        D3D_KNNR_CASE(1)
+        D3D_KNNR_CASE(2)
+        D3D_KNNR_CASE(4)
+        D3D_KNNR_CASE(8)
+        default:
+            d3d_set_error_("d3d_knn_radius: k_max must be 1, 2, 4 or 8");
+            return D3D_EINVAL;
+    }
+#undef D3D_KNNR_CASE
     D3D_LAUNCH_CHECK();
 }
 

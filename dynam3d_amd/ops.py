@@ -227,10 +227,15 @@ class HipOps:
                                                        self._stream()))
 
     # -- a8 -------------------------------------------------------------------------------------
-    def knn(self, points, point_stride, n_points, queries, query_stride, n_queries, k, n_batch, max_queries, k_max):
+    def knn(self, points, point_stride, n_points, queries, query_stride, n_queries, k, n_batch, max_queries, k_max, radius=None):
+        """`radius`: only neighbours inside it are needed (the renderer discards the rest): d3d_knn_radius, exact inside the radius."""
         dev = points.device
         d2 = torch.full((n_batch, max_queries, k_max), float("inf"), dtype=torch.float32, device=dev)
         idx = torch.full((n_batch, max_queries, k_max), -1, dtype=torch.int32, device=dev)
+        if radius is not None:
+            self._ck(self.lib.d3d_knn_radius(_ptr(points), point_stride, _ptr(n_points), _ptr(queries), query_stride, _ptr(n_queries), _ptr(k),
+                                             n_batch, max_queries, k_max, float(radius), _ptr(d2), _ptr(idx), self._stream()))
+            return d2, idx
         self._ck(self.lib.d3d_knn(_ptr(points), point_stride, _ptr(n_points), _ptr(queries), query_stride, _ptr(n_queries), _ptr(k),
                                   n_batch, max_queries, k_max, _ptr(d2), _ptr(idx), self._stream()))
         return d2, idx

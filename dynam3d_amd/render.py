@@ -33,6 +33,8 @@ def _p(t):
 
 
 class FieldRenderer:
+    RADIUS_KNN = True
+
     def __init__(self, sd: Dict[str, torch.Tensor], device="cuda", view_hw=(12, 12), n_samples=501, n_importance=8, k=4, radius=1.0,
                  near=0.0, far=10.0, hfov=90.0, vfov=90.0, width=768):
         self.lib = _lib.load()
@@ -120,7 +122,10 @@ class FieldRenderer:
         pose3 = np.array([[np.float32(math.cos(-h)), np.float32(math.sin(-h)), np.float32(h)] for h in batch_heading], np.float32)
         ident = all(s == i for i, s in enumerate(slots))
         pts = pools.rows_pos if ident else pools.rows_pos.index_select(0, i32t(slots).long()).contiguous()
-        d2, idx = ops.knn(pts, pools.n_cap * 3, i32t(n_rows), ray, R * N * 3, i32t([R * N] * B), i32t([K] * B), B, R * N, K)   # PRE-FF:540
+        # PRE-FF:540: neighbours at >= radius are discarded by d3d_ray_topk right behind this query, so the radius-limited kernel serves
+        # (identical inside the radius; RADIUS_KNN = False: the exact brute-force d3d_knn, the A/B baseline)
+        kw = {"radius": self.radius} if self.RADIUS_KNN else {}
+        d2, idx = ops.knn(pts, pools.n_cap * 3, i32t(n_rows), ray, R * N * 3, i32t([R * N] * B), i32t([K] * B), B, R * N, K, **kw)
         n_rays = B * R
         topk = torch.empty((n_rays, S), dtype=torch.int32, device=dev)
         sidx = torch.empty((n_rays, S, K), dtype=torch.int32, device=dev)

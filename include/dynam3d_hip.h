@@ -162,6 +162,13 @@ int32_t d3d_frustum_mask(const float* points_d, int64_t n, const float* depth_d,
 int32_t d3d_knn(const float* points_d, int64_t point_stride, const int32_t* n_points_d, const float* queries_d,
                 int64_t query_stride, const int32_t* n_queries_d, const int32_t* k_d, int32_t n_batch,
                 int32_t max_queries, int32_t k_max, float* d2_d, int32_t* idx_d, void* stream);
+/* a21  the renderer's query (PRE-FF:540-566: `patch_tree.query(sample_points, 4)` followed by "distance >= 1 m -> index -1, distance 1"):
+ * same arguments and layout as d3d_knn, but only neighbours INSIDE `radius` are guaranteed -- every slot whose d^2 < radius^2 holds
+ * exactly what d3d_knn reports there (same d^2 bits, same index, same order); a slot beyond the radius holds a farther point or
+ * (inf, -1).  A workgroup boxes its 256 consecutive queries and scores only the points inside the box grown by the radius. */
+int32_t d3d_knn_radius(const float* points_d, int64_t point_stride, const int32_t* n_points_d, const float* queries_d,
+                       int64_t query_stride, const int32_t* n_queries_d, const int32_t* k_d, int32_t n_batch,
+                       int32_t max_queries, int32_t k_max, float radius, float* d2_d, int32_t* idx_d, void* stream);
 
 /* a7/a10 geometry: per-group centroid (float64 sequential mean, rounded once) + 7-vector
  * [pos-centroid, |pos|, sin dir, cos dir, scale] for every member token (VLN-FF:582-591, 662-673).

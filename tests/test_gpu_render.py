@@ -82,3 +82,36 @@ def test_tcnn_network_shim():
     with torch.no_grad():
         y2 = Network.from_flat_params(768, 769, cfg, flat)(x.cuda()).float().cpu()
     assert torch.equal(y, y2)
+
+
+def test_radius_knn_equals_brute_force_inside_the_radius():
+    """d3d_knn_radius (the renderer's query: a workgroup boxes its 256 consecutive queries and scores only the points inside the box grown
+    by the radius) against d3d_knn: every neighbour with d^2 < radius^2 identical in value, index and position; slots beyond the radius hold
+    a farther point or (inf, -1) -- what d3d_ray_topk turns into "missing" either way.  Ray-like queries (coherent) and scattered ones,
+    ties, empty / tiny point sets, several batches."""
+    import numpy as np
+    import torch
+    from dynam3d_amd.ops import HipOps
+    ops = HipOps()
+    rng = np.random.default_rng(0)
+    B, NP, NQ, K, r = 3, 9000, 144 * 501, 4, 1.0
+    pts = rng.uniform(-6, 6, (B, NP, 3)).astype(np.float32)
+    pts[:, 100:140] = pts[:, 60:100]                                   # exact duplicates -> ties on d^2: the lower index must win
+    pts[1, 5000:] = -10000.0                                           # tomb-stoned rows
+    n_points = np.array([NP, 5000, 37], np.int32)
+    t = np.linspace(0.0, 10.0, 501, dtype=np.float32)
+    dirs = rng.normal(size=(B, 144, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    q = (rng.uniform(-2, 2, (B, 1, 1, 3)).astype(np.float32) + dirs[:, :, None, :] * t[None, None, :, None]).reshape(B, NQ, 3)
+    q[2] = rng.uniform(-6, 6, (NQ, 3)).astype(np.float32)             # batch 2: scattered queries (the box is the whole scene)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device="cuda")
+    P, Q = torch.from_numpy(pts).cuda(), torch.from_numpy(q).cuda()
+    args = (P, NP * 3, i32(n_points), Q, NQ * 3, i32([NQ, NQ, 1000]), i32([K, K, 2]), B, NQ, K)
+    d2e, ie = ops.knn(*args)
+    d2r, ir = ops.knn(*args, radius=r)
+    d2e, ie, d2r, ir = (x.cpu().numpy() for x in (d2e, ie, d2r, ir))
+    inside = d2e < r * r
+    assert inside.sum() > 10000
+    assert np.array_equal(d2r[inside].view(np.uint32), d2e[inside].view(np.uint32)) and np.array_equal(ir[inside], ie[inside])
+    assert (d2r[~inside] >= r * r).all()                               # never a spurious neighbour inside the radius
+    # and the renderer's own outputs do not depend on which kernel answered (FieldRenderer.RADIUS_KNN): covered by test_render_* above

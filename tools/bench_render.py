@@ -25,12 +25,24 @@ posn = [[float(rng.uniform(-1, 1)), 0.0, float(rng.uniform(-1, 1))] for _ in ran
 head = [float(rng.uniform(0, 6.28)) for _ in range(B)]
 def run():
     return r.render(pools, list(range(B)), [N] * B, posn, head, ops)
-for _ in range(3): run()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(10): run()
-torch.cuda.synchronize()
-print(f"render_view_3d_patch B={B} views, N={N} patches/env: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms per call ({(time.perf_counter() - t0) / 10 / B * 1e3:.2f} ms per view)")
+def timed_calls():
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10): run()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / 10 * 1e3
+if os.environ.get("RENDER_AB", "1") == "1":                      # radius-limited KNN (default) against the exact brute-force query, alternating
+    ab = {True: [], False: []}
+    for rep in range(3):
+        for flag in (False, True):
+            FieldRenderer.RADIUS_KNN = flag
+            ab[flag].append(timed_calls())
+    FieldRenderer.RADIUS_KNN = True
+    same = all(torch.equal(a, b) for a, b in zip(run()[:2], (lambda: (setattr(FieldRenderer, "RADIUS_KNN", False), run(), setattr(FieldRenderer, "RADIUS_KNN", True))[1])()[:2]))
+    print(f"render call, brute-force d3d_knn: {'/'.join(f'{t:.2f}' for t in ab[False])} ms | d3d_knn_radius: {'/'.join(f'{t:.2f}' for t in ab[True])} ms | identical feature map + positions: {same}")
+ms = timed_calls()
+print(f"render_view_3d_patch B={B} views, N={N} patches/env: {ms:.2f} ms per call ({ms / B:.2f} ms per view)")
 x = (torch.randn(B * 1152, 768, device="cuda") * 0.5).half()
 def tm(fn, n=30):
     for _ in range(5): fn()
