@@ -31,9 +31,11 @@ HIP_SOURCES = [
     ("render_kernels.hip", ["-ffp-contract=off"]),
     ("mlp_kernels.hip", ["-ffp-contract=fast"]),
     ("segment_kernels.hip", ["-ffp-contract=off"]),
+    ("ff_plan_kernels.hip", ["-ffp-contract=off"]),
 ]
 CPP_SOURCES = ["ff_state.cpp", "d3d_error.cpp", "phi3_decode.cpp", "mlp_forward.cpp"]
-HOST_CPP_SOURCES = ["ff_state.cpp", "d3d_error.cpp"]      # the CPU-only bookkeeping library (no device entry points)
+HOST_CPP_SOURCES = ["ff_state.cpp", "d3d_error.cpp", "ff_plan_host.cpp"]      # the CPU-only bookkeeping library (no device entry points;
+                                                                          # ff_plan_host.cpp = the device planner's source on host arrays, tests only)
 
 
 def _newer(src, dst):

@@ -758,7 +758,7 @@ __global__ void k_scatter_rows(float* __restrict__ pool, int64_t cap, int D, con
                                const int32_t* __restrict__ src_row) {
     const int t = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int lane = threadIdx.x & (WAVE - 1);
-    if (t >= T) return;
+    if (t >= T || row[t] < 0) return;                          // row -1: nothing to store for this source row (device-planned scatters)
     float* dst = pool + ((int64_t)slot[t] * cap + row[t]) * D;
     const float* s = src + (size_t)(src_row ? src_row[t] : t) * D;
     if ((D & 3) == 0) {

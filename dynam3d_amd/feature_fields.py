@@ -19,6 +19,7 @@ trajectories match; `compat='fixed'` keeps id == row.
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional
 
@@ -27,6 +28,7 @@ import torch
 
 from .ops import pinhole_unproject_rows, pinhole_views, FTS, CameraTables, Pools, make_pose
 from ._ffstate import FFState
+from .ff_plan import REPORT_WORDS, DevicePlanner
 from .ff_dense import FFDense
 from .modules import RefreshOnChange, install_param
 
@@ -69,11 +71,14 @@ class Feature_Fields(RefreshOnChange):
 
     def __init__(self, batch_size: int = 1, device="cuda", state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  compat: str = "reference", max_steps: int = 64, max_views: int = 1, m_cap: int = 4096, z_cap: int = 2048,
-                 ops=None, segmenter=None, variant: str = "vln", seed: int = 0):
+                 ops=None, segmenter=None, variant: str = "vln", seed: int = 0, planner: Optional[str] = None):
         """variant: "vln" = the VLN class's argument defaults (VLN-FF:22-46, 2 merge proposals); "pretrain" = the Pretrain
         class's (PRE-FF:29-45: `num_proposal_instances` 4) -- the memory update itself is the same state machine.
         `state_dict=None`: seeded synthetic parameters (the reference constructs with random initial weights and loads
-        `dynam3d.pth` afterwards, VLN-POL:77-80)."""
+        `dynam3d.pth` afterwards, VLN-POL:77-80).
+        planner: "device" = the id / dict bookkeeping runs on the GPU next to the float kernels (csrc/ff_plan.h: one small report read
+        back per view); "host" = the C++ state machine (csrc/ff_state.cpp: the update waits for the host before every decision; the
+        training branch needs it).  Default: $D3D_FF_PLANNER, else "host"."""
         super().__init__()
         self.device = torch.device(device)
         self.args = _args_namespace()
@@ -100,7 +105,13 @@ class Feature_Fields(RefreshOnChange):
                 install_param(self, k, v.detach().to(self.device, torch.float32).contiguous())
         self._init_refresh_hooks()
         self.refresh()
-        self.state = FFState(ops.lib, compat, self.P, self.args.num_proposal_instances)
+        self.planner = planner or os.environ.get("D3D_FF_PLANNER", "host")
+        if self.planner not in ("host", "device"):
+            raise ValueError("planner must be 'host' or 'device'")
+        if self.planner == "device":
+            self.state = DevicePlanner(compat, self.P, self.args.num_proposal_instances, self.device)
+        else:
+            self.state = FFState(ops.lib, compat, self.P, self.args.num_proposal_instances)
         self._cam: Optional[CameraTables] = None
         self.pools: Optional[Pools] = None
         self.reset(batch_size)
@@ -166,12 +177,15 @@ class Feature_Fields(RefreshOnChange):
     # ---- lifecycle (VLN-FF:186-240) ------------------------------------------------------------
     def reset(self, batch_size: int = 1):
         self.batch_size = batch_size
-        self.state.reset(batch_size)
         tomb = [int(math.floor(-10000.0 / L)) for L in self.cell_len]
-        self.state.set_tomb_cell(tomb)
         n_cap = self.P * self.max_views * self.max_steps
         if self.pools is None or self.pools.rows_pos.shape[0] < batch_size or self.pools.n_cap != n_cap:
             self.pools = Pools.allocate(batch_size, n_cap, self._m_cap, self._z_cap, self.device)
+        if self.planner == "device":
+            self.state.reset(batch_size, self.pools.n_cap, self.pools.m_cap, self.pools.z_cap, tomb)
+        else:
+            self.state.reset(batch_size)
+            self.state.set_tomb_cell(tomb)
         self.slots: List[int] = list(range(batch_size))
         self.keep_target_waypoint = [None for _ in range(batch_size)]
         self.history_actions = [["none\n"] * 4 for _ in range(batch_size)]      # per-row lists
@@ -191,7 +205,10 @@ class Feature_Fields(RefreshOnChange):
 
     def delete_feature_fields(self):
         self.pools = None
-        self.state.reset(0)
+        if self.planner == "device":
+            self.state.reset(0, 0, 0, 0)
+        else:
+            self.state.reset(0)
         self.slots, self.keep_target_waypoint, self.history_actions, self._tree_slots = [], [], [], []
         self.batch_size = 0
 
@@ -264,6 +281,8 @@ class Feature_Fields(RefreshOnChange):
         new.rows_pos[:, :n], new.rows_fts[:, :n], new.rows_dir[:, :n], new.rows_scale[:, :n] = old.rows_pos, old.rows_fts, old.rows_dir, old.rows_scale
         new.inst_pos, new.inst_fts, new.tree_pos, new.zone_pos, new.zone_fts = old.inst_pos, old.inst_fts, old.tree_pos, old.zone_pos, old.zone_fts
         self.pools = new
+        if self.planner == "device":
+            self.state.ensure(R=new_cap)
 
     def _grow_slots(self, which: str, need: int):
         """The reference's instance / zone stores grow without bound (torch.cat, VLN-FF:645-648, 737); these pools double."""
@@ -278,10 +297,14 @@ class Feature_Fields(RefreshOnChange):
             new = torch.zeros((old.shape[0], new_cap) + tuple(old.shape[2:]), dtype=old.dtype, device=old.device)
             new[:, :cap] = old
             setattr(p, n, new)
+        if self.planner == "device":
+            self.state.ensure(**({"M": new_cap} if which == "inst" else {"Z": new_cap}))
 
     def _snapshot_tree(self):
         # kd-tree rebuild (VLN-FF:396, 815): the tree owns a COPY of the instance centres
         self.pools.tree_pos.copy_(self.pools.inst_pos)
+        if self.planner == "device":                                   # (the device planner marks the rebuild itself: apply_hits / plan_zones)
+            return
         for e in range(self.batch_size):
             self._tree_slots[e] = self.state.end_view(e)
 
@@ -304,6 +327,8 @@ class Feature_Fields(RefreshOnChange):
         a = self.args
         intr = (float(np.float32(Wd / np.tan(np.deg2rad(a.input_hfov) / 2.0) / 2.0)),
                 float(np.float32(Hd / np.tan(np.deg2rad(a.input_vfov) / 2.0) / 2.0)), Wd / 2.0, Hd / 2.0)
+        if self.planner == "device":
+            return self._delete_device(depth, batch_position, batch_heading, batch_camera_intrinsic, batch_extrinsic, num_of_views, view_ids, pinhole, intr)
         for ix in range(num_of_views):
             envs = [e for e in range(B) if st.count(e, st.ROWS) > 0]
             if not envs:
@@ -341,6 +366,30 @@ class Feature_Fields(RefreshOnChange):
                 s, r = self._i32(dz_s), self._i32(dz_r)
                 self.ops.fill_rows(pools.zone_pos, s, r, -10000.0)
                 self.ops.fill_rows(pools.zone_fts, s, r, 0.0)
+        self._snapshot_tree()
+
+    def _delete_device(self, depth, batch_position, batch_heading, batch_camera_intrinsic, batch_extrinsic, num_of_views, view_ids, pinhole, intr):
+        """The same pass with the cascade on the device (d3d_ffdev_apply_hits consumes the frustum kernel's hit list in place): no
+        device-to-host read."""
+        B, pl, pools, a = self.batch_size, self.state, self.pools, self.args
+        envs = list(range(B))
+        n_rows = [pl.n_rows[e] for e in envs]
+        mx = max(n_rows, default=0)
+        if mx == 0:
+            return
+        slot, n_rows_d = self._i32_many([self.slots[e] for e in envs], n_rows)
+        for ix in range(num_of_views):
+            hits = torch.empty((B, mx), dtype=torch.int32, device=self.device)
+            n_hits = torch.zeros((B,), dtype=torch.int32, device=self.device)
+            d_ix = depth[:, ix].contiguous()
+            if pinhole:
+                views = torch.from_numpy(pinhole_views([_host(batch_camera_intrinsic[e][ix]) for e in envs],
+                                                       [_host(batch_extrinsic[e][ix]) for e in envs])).to(self.device)
+                self.ops.frustum_cull_pinhole(pools, slot, n_rows_d, mx, d_ix, views, 0.0, float(a.deleted_frustum_distance), 0.1, hits, n_hits)
+            else:
+                pose = self._poses(batch_position, batch_heading, envs, view_offset=0.0 if view_ids is None else view_ids[ix] * (-math.pi / 6))
+                self.ops.frustum_cull(pools, slot, n_rows_d, mx, d_ix, pose, intr, 0.0, float(a.deleted_frustum_distance), 0.1, hits, n_hits)
+            self.ops.ffdev_apply_hits(pl, slot, hits, n_hits, pools)         # VLN-FF:362-393 + the rebuild mark of VLN-FF:396
         self._snapshot_tree()
 
     # ---- a6 contract ------------------------------------------------------------------------------------
@@ -399,11 +448,18 @@ class Feature_Fields(RefreshOnChange):
         slots_h = np.array([self.slots[e] for e in envs], np.int32)
         slot = self._i32(slots_h)
         self.last_debug = []
+        dev_plan = self.planner == "device"
+        if dev_plan and trainer is not None:
+            raise RuntimeError("is_training=True needs Feature_Fields(planner='host'): the loss terms read the dictionaries on the host")
         for ix in range(V):
             self._grow_rows(max(st.count(e, st.ROWS) for e in envs) + P)
             pools = self.pools
-            rb, k0, has_tree = zip(*[st.begin_view(e) for e in envs])
-            k0 = [k if t else 0 for k, t in zip(k0, has_tree)]
+            if dev_plan:
+                rb = [st.n_rows[e] for e in envs]
+                k0_d, tree_slots_d = ops.ffdev_begin_view(st, slot)            # VLN-FF:532, on the device
+            else:
+                rb, k0, has_tree = zip(*[st.begin_view(e) for e in envs])
+                k0 = [k if t else 0 for k, t in zip(k0, has_tree)]
             row_base = self._i32(rb)        # (re-bound below to a slice of this view's one index upload)
             if pinhole:                                                                                   # PRE-FF:905-916
                 cams = pinhole_unproject_rows([_host(batch_camera_intrinsic[e][ix]) for e in envs], [_host(batch_rot[e][ix]) for e in envs],
@@ -429,8 +485,17 @@ class Feature_Fields(RefreshOnChange):
             grp_off = np.concatenate([[0], np.cumsum(counts.reshape(-1))]).astype(np.int32)
             G = len(envs) * n_max
             valid_g = np.nonzero(counts.reshape(-1) > 0)[0]
-            tok_slot_d, tok_row_d, grp_off_d, valid_g_d, n_seg_d, k0_d, tree_slots_d = self._i32_many(tok_slot, tok_row, grp_off, valid_g, n_seg, k0,
-                                                                                                    self._tree_slots)
+            if dev_plan:
+                seg_off = np.concatenate([np.zeros((len(envs), 1), np.int64), np.cumsum(counts, 1)], 1)
+                tok_slot_d, tok_row_d, grp_off_d, valid_g_d, n_seg_d, order_d, tok_seg_d, seg_off_d = self._i32_many(
+                    tok_slot, tok_row, grp_off, valid_g, n_seg, order, np.take_along_axis(segm, order, 1), seg_off)
+                self._grow_slots("inst", max(st.n_slots) + n_max)               # the planner may open n_seg new slots / zones per environment
+                self._grow_slots("zone", max(max(st.n_zrows), max(st.n_zids)) + n_max)
+                st.ensure(E=max(st.n_edges) + max(st.n_slots) + n_max)
+                pools = self.pools
+            else:
+                tok_slot_d, tok_row_d, grp_off_d, valid_g_d, n_seg_d, k0_d, tree_slots_d = self._i32_many(tok_slot, tok_row, grp_off, valid_g, n_seg, k0,
+                                                                                                        self._tree_slots)
             centroid, cell, geom7 = ops.group_stats7(pools, tok_slot_d, tok_row_d, grp_off_d, G, self.cell_len)
             tok_fts = ops.gather_fts(pools, tok_slot_d, tok_row_d)
             if trainer is not None:                                           # differentiable encoding + loss terms of this view (PRE-FF:940-1008)
@@ -450,19 +515,26 @@ class Feature_Fields(RefreshOnChange):
             d2, idx = ops.knn(tree_pts, pools.m_cap * 3, tree_slots_d, centroid, n_max * 3, n_seg_d, k0_d, len(envs), n_max, k_max)
             pair_e, pair_s, pair_j = [], [], []
             for j_, e in enumerate(envs):
-                if k0[j_] > 0:
-                    ss, jj = np.meshgrid(np.arange(n_seg[j_]), np.arange(k0[j_]), indexing="ij")
+                kk = K if dev_plan else k0[j_]       # device planner: every (segment, proposal slot); the planner reads the first k of them
+                if kk > 0:
+                    ss, jj = np.meshgrid(np.arange(n_seg[j_]), np.arange(kk), indexing="ij")
                     pair_e.append(np.full(ss.size, j_)); pair_s.append(ss.reshape(-1)); pair_j.append(jj.reshape(-1))
             logits_full = torch.zeros((len(envs), n_max, k_max, 2), dtype=torch.float32, device=self.device)
             if pair_e:
                 pe_h, ps_h, pj_h = (np.concatenate(x) for x in (pair_e, pair_s, pair_j))
                 pe, ps_, pj, pair_new, pair_slot = self._i32_many(pe_h, ps_h, pj_h, pe_h * n_max + ps_h, slots_h[pe_h])   # (int32 index tensors)
                 pair_inst = idx[pe, ps_, pj].contiguous()
+                if dev_plan:
+                    pair_inst.clamp_(min=0)                                   # proposal slots past k0 hold -1: any row will do, their logits are never read
                 if trainer is not None:                                       # discriminator loss; the memory merges by ground truth (PRE-FF:1029-1047)
                     logits_full[pe, ps_, pj] = trainer.merge(pools, pair_slot, pe, ps_, pj, pair_inst, len(envs))
                 else:
                     x = ops.merge_input(pools, new_fts, centroid, pair_slot, pair_inst, pair_new)
                     logits_full[pe, ps_, pj] = self.dense.merge_logits(x)
+            if dev_plan:
+                self._finish_view_device(envs, slot, slots_h, order_d, tok_seg_d, seg_off_d, n_seg_d, n_max, k_max, k0_d, d2, idx, logits_full, cell, centroid,
+                                         new_fts, rb)
+                continue
             d2_h, idx_h, logits_h, cell_h = d2.cpu().numpy(), idx.cpu().numpy(), logits_full.cpu().numpy(), cell.cpu().numpy()  # sync #2
 
             # ---- bookkeeping: new ids / merges ---------------------------------------------------------
@@ -519,24 +591,73 @@ class Feature_Fields(RefreshOnChange):
                 ops.scatter_rows(pools.zone_fts, gs, gr, zfts)
             self._snapshot_tree()
 
+    def _finish_view_device(self, envs, slot, slots_h, order_d, tok_seg_d, seg_off_d, n_seg_d, n_max, k_max, k0_d, d2, idx, logits, cell, centroid, new_fts, rb):
+        """New / merge bookkeeping and the zone update of one view with the planner on the device (VLN-FF:623-756): every decision is a
+        kernel (csrc/ff_plan.h) fed by the kernels before it; the host reads ONE report (sizes of the merged and the zone sets) and then
+        launches the two set encoders."""
+        st, ops, pools, B, P = self.state, self.ops, self.pools, len(envs), self.P
+        G_ub = B * n_max
+        rows_stride = max(rb) + P
+        # one int32 block for everything the host reads back: report words | totals (merge) | totals (zones) | group offsets x 2
+        rep = torch.zeros((B * REPORT_WORDS + 2 * (2 + B) + 2 * (G_ub + 1),), dtype=torch.int32, device=self.device)
+        o = B * REPORT_WORDS
+        report, tot_m, tot_z = rep[:o], rep[o:o + 2 + B], rep[o + 2 + B:o + 2 * (2 + B)]
+        o += 2 * (2 + B)
+        goff, zgoff = rep[o:o + G_ub + 1], rep[o + G_ub + 1:]
+        seg_slot, dirty_inst, dirty_off, dirty_rows = ops.ffdev_plan_merge(st, slot, order_d, tok_seg_d, seg_off_d, n_seg_d, n_max, k_max, k0_d, d2, idx, logits,
+                                                                           cell, rows_stride, report)
+        grp_slot_new = self._i32(np.repeat(slots_h, n_max))
+        ops.scatter_rows(pools.inst_pos, grp_slot_new, seg_slot.view(-1), centroid)                 # VLN-FF:643-648 (rows -1 = merged segments: skipped)
+        ops.scatter_rows(pools.inst_fts, grp_slot_new, seg_slot.view(-1), new_fts)
+        ts, tr, gs, gi = ops.ffdev_flatten_merge(slot, n_max, dirty_inst, dirty_off, dirty_rows, report, goff, tot_m)
+        _, mcell, mgeom = ops.group_stats7(pools, ts, tr, goff, G_ub, self.cell_len, pools.inst_pos, gs, gi)    # merged centroids -> inst_pos, their cells
+        zone_row, zone_mode, zone_off, zone_mem = ops.ffdev_plan_zones(st, slot, dirty_inst, mcell, cell, n_seg_d, n_max, pools.m_cap, report)
+        zts, zti, zmode, zgs, zgr = ops.ffdev_flatten_zones(slot, n_max, zone_row, zone_mode, zone_off, zone_mem, report, zgoff, tot_z)
+        rep_h = rep.cpu().numpy()                                                                   # the view's ONE device-to-host read
+        for j_, e in enumerate(envs):
+            st.n_rows[e] += P
+        o = B * REPORT_WORDS
+        st.take_report_envs(envs, rep_h[:o].reshape(B, REPORT_WORDS))
+        n_m, T_m = int(rep_h[o]), int(rep_h[o + 1])
+        n_z, T_z = int(rep_h[o + 2 + B]), int(rep_h[o + 2 + B + 1])
+        o += 2 * (2 + B)
+        goff_h, zgoff_h = rep_h[o:o + G_ub + 1], rep_h[o + G_ub + 1:]
+        if n_m:                                                                                      # VLN-FF:662-688
+            mfts = ops.gather_fts(pools, ts[:T_m], tr[:T_m])
+            merged = self.dense.encode_patch_sets(mfts, mgeom[:T_m], np.diff(goff_h[:n_m + 1]).tolist())
+            ops.scatter_rows(pools.inst_fts, gs[:n_m], gi[:n_m], merged)
+        if n_z:                                                                                      # VLN-FF:694-756 / 777-812
+            z_lens = np.diff(zgoff_h[:n_z + 1]).tolist()
+            geom4 = ops.group_stats4(pools, zts[:T_z], zti[:T_z], zgoff[:n_z + 1], zmode[:n_z], zgs[:n_z], zgr[:n_z], n_z, self.cell_len)
+            ifts = ops.gather_rows(pools.inst_fts, zts[:T_z], zti[:T_z]) if T_z else torch.zeros((0, FTS), device=self.device)
+            zfts = self.dense.encode_zone_sets(ifts, geom4, z_lens)
+            ops.scatter_rows(pools.zone_fts, zgs[:n_z], zgr[:n_z], zfts)
+        self._snapshot_tree()
+
     # ---- a12 (VLN-FF:818-862) -----------------------------------------------------------------------------------
     @torch.no_grad()
     def get_environment_features(self, agent_position, agent_heading_angle, instance_distance=5.0, zone_distance=100.0):
         B, st, pools = self.batch_size, self.state, self.pools
         envs = list(range(B))
-        ids = [st.live_ids(e) for e in envs]
         pose = self._poses(agent_position, agent_heading_angle, envs)
         slot = self._i32([self.slots[e] for e in envs])
         out = {}
-        for which, (pp, pf, radius, key) in enumerate(((pools.inst_pos, pools.inst_fts, instance_distance, "instance"),
-                                                       (pools.zone_pos, pools.zone_fts, zone_distance, "zone"))):
-            n_ids = np.array([len(i[which]) for i in ids], np.int32)
-            mx = max(1, int(n_ids.max()))
-            pad = np.zeros((B, mx), np.int32)
-            for e in envs:
-                pad[e, :n_ids[e]] = ids[e][which]
-            rel, fts, kept, count = self.ops.agent_frame_compact(pp, pf, slot, self._i32(pad), self._i32(n_ids), pose, float(radius))
-            out[key] = (rel, fts, kept, count)
+        if self.planner == "device":                                       # dict order (VLN-FF:825, 844) ranked on the device
+            mx = max(1, max(st.n_slots, default=0), max(st.n_zids, default=0))
+            inst_ids, n_inst, zone_ids, n_zone = self.ops.ffdev_live_ids(st, slot, mx)
+            out["instance"] = self.ops.agent_frame_compact(pools.inst_pos, pools.inst_fts, slot, inst_ids, n_inst, pose, float(instance_distance))
+            out["zone"] = self.ops.agent_frame_compact(pools.zone_pos, pools.zone_fts, slot, zone_ids, n_zone, pose, float(zone_distance))
+        else:
+            ids = [st.live_ids(e) for e in envs]
+            for which, (pp, pf, radius, key) in enumerate(((pools.inst_pos, pools.inst_fts, instance_distance, "instance"),
+                                                           (pools.zone_pos, pools.zone_fts, zone_distance, "zone"))):
+                n_ids = np.array([len(i[which]) for i in ids], np.int32)
+                mx = max(1, int(n_ids.max()))
+                pad = np.zeros((B, mx), np.int32)
+                for e in envs:
+                    pad[e, :n_ids[e]] = ids[e][which]
+                rel, fts, kept, count = self.ops.agent_frame_compact(pp, pf, slot, self._i32(pad), self._i32(n_ids), pose, float(radius))
+                out[key] = (rel, fts, kept, count)
         ci, cz = out["instance"][3].cpu().numpy(), out["zone"][3].cpu().numpy()      # sync #4: Ni, Nz
         return {
             "batch_instance_fts": [out["instance"][1][e, :ci[e]] for e in envs],
@@ -557,7 +678,7 @@ class Feature_Fields(RefreshOnChange):
     # ---- test / debug export ------------------------------------------------------------------------------------------
     def export_env(self, e: int):
         st, pools, s = self.state, self.pools, self.slots[e]
-        ex = st.export(e)
+        ex = st.export(s if self.planner == "device" else e)
         nr, ns, nz = st.count(e, st.ROWS), st.count(e, st.SLOTS), st.count(e, st.ZROWS)
         ex.update(rows_pos=pools.rows_pos[s, :nr].cpu().numpy(), ipos=pools.inst_pos[s, :ns].cpu().numpy(),
                   ifts=pools.inst_fts[s, :ns].cpu().numpy(), zpos=pools.zone_pos[s, :nz].cpu().numpy(),

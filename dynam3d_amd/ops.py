@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .ff_plan import FFDevOps
 
 FTS = 768
 POSE_FLOATS = 8
@@ -113,7 +114,7 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-class HipOps:
+class HipOps(FFDevOps):
     name = "hip"
 
     def __init__(self):

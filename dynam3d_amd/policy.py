@@ -159,14 +159,16 @@ class Dynam3D_VLN(RefreshOnChange):
 
     def __init__(self, cfg: PolicyConfig = PolicyConfig(), weights: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0,
                  device="cuda", batch_size: int = 1, ops=None, tokenizer=None, segmenter=None, max_steps: int = 64,
-                 depth_encoder: Optional[torch.nn.Module] = None):
+                 depth_encoder: Optional[torch.nn.Module] = None, ff_planner: Optional[str] = None):
+        """ff_planner: `Feature_Fields(planner=...)` -- "device" / "host" bookkeeping of the 3D memory (default: $D3D_FF_PLANNER, else host)."""
         super().__init__()
         self.cfg, self.device = cfg, torch.device(device)
         if self.device.type == "cuda" and cfg.hip_dense:
             D.enable_hip_kernels(["all"])             # before the towers are built: they lay their weights out for these kernels
         sd = weights if weights is not None else synth_policy_weights(cfg, seed)
         ff_sd = {k: sd[k] for k, _ in ff_param_spec(768)}
-        self.feature_fields = Feature_Fields(batch_size, device, ff_sd, compat=cfg.compat, ops=ops, segmenter=segmenter, max_steps=max_steps)
+        self.feature_fields = Feature_Fields(batch_size, device, ff_sd, compat=cfg.compat, ops=ops, segmenter=segmenter, max_steps=max_steps,
+                                             planner=ff_planner)
         self.feature_fields.requires_grad_(False)                                             # VLN-POL:150-151 ("Avoid DDP bug")
         self.ops = self.feature_fields.ops
         width, hidden = 768, cfg.llm.hidden

@@ -512,6 +512,60 @@ int32_t d3d_ff_export_members(const d3d_ff* ff, int32_t env, int32_t which /*0 i
                               int32_t* off_h, int32_t* flat_h, int64_t flat_cap);
 int32_t d3d_ff_export_zone_keys(const d3d_ff* ff, int32_t env, int32_t* cells_h /*(n,3)*/, int32_t* ids_h, int32_t cap);
 
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident planner of the memory update (csrc/ff_plan.h + ff_plan_kernels.hip): the same dict / id semantics as d3d_ff_*
+ * above (VLN-FF:362-393 deletion cascade, 433-475 lowest unused ids, 623-691 new / merge bookkeeping, 694-756 zones, 825/844 dict
+ * order), decided ON THE GPU from the kernels' own outputs -- the frustum hit list, the KNN table, the merge logits, the cells --, so
+ * that an update reads back ONE small report per view instead of synchronising before every decision.  All pointers are device
+ * pointers; the state is a set of int32 arrays owned by the caller, one row per storage slot:
+ *   hdr [S][16] | rows [S][3][R]: owner, stamp_of_pid, pid_of_stamp | inst [S][6][M]: live, stamp, members, cell x/y/z |
+ *   zone [S][8][Z]: live, stamp, key stamp, snapshot size, visit mark, key x/y/z | edges [S][2][2][E]: zone-member snapshots
+ *   (double-buffered) | scratch [S][W], W >= max(8 * P + 16, M + Z).   A fresh slot is all zero except owner / pid_of_stamp = -1.
+ * `slot[e]` maps environment e of the batch to its storage slot; one workgroup per environment, asynchronous on `stream`.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct d3d_ffdev_state {
+    int32_t *hdr, *rows, *inst, *zone, *edges, *scratch;
+    int32_t R, M, Z, E, W;
+    int32_t compat_fixed, P, K;      /* compat as d3d_ff_create; P patches per view; K = num_proposal_instances */
+    int32_t tomb[3];                 /* cell of a tomb-stoned position: floor(-10000 / cell_len) */
+} d3d_ffdev_state;
+#define D3D_FFDEV_HDR_WORDS 16
+#define D3D_FFDEV_REPORT_WORDS 16
+
+/* k0[e] = min(#live instances, K) if the env has a tree else 0 (VLN-FF:532); tree_slots[e] = points in its tree */
+int32_t d3d_ffdev_begin_view(const d3d_ffdev_state* st, const int32_t* slot, int32_t B, int32_t* k0, int32_t* tree_slots, void* stream);
+/* the cascade behind d3d_frustum_cull's hit list (hits [B][hits_stride], n_hits [B]): VLN-FF:362-393; ends with the tree rebuild mark */
+int32_t d3d_ffdev_apply_hits(const d3d_ffdev_state* st, const int32_t* slot, int32_t B, const int32_t* hits, int64_t hits_stride,
+                             const int32_t* n_hits, float* inst_pos, float* inst_fts, int64_t m_cap, float* zone_pos, float* zone_fts,
+                             int64_t z_cap, int32_t fts_dim, void* stream);
+/* VLN-FF:604-691 for one view.  order / tok_seg [B][P]: the patches sorted by (segment, patch) and their segments; seg_off
+ * [B][n_max+1]; d2 / idx [B][n_max][k_max]; logits [B][n_max][k_max][2]; new_cells [B*n_max][3].  Out: seg_slot [B][n_max] (slot of
+ * the NEW instance of a segment, -1 = merged), dirty_inst [B][n_max], dirty_off [B][n_max+1], dirty_rows [B][rows_stride] (member
+ * rows of the merged instances, push order), report [B][16]. */
+int32_t d3d_ffdev_plan_merge(const d3d_ffdev_state* st, const int32_t* slot, int32_t B, const int32_t* order, const int32_t* tok_seg,
+                             const int32_t* seg_off, const int32_t* n_seg, int32_t n_max, int32_t k_max, const int32_t* k0,
+                             const float* d2, const int32_t* idx, const float* logits, const int32_t* new_cells, int32_t* seg_slot,
+                             int32_t* dirty_inst, int32_t* dirty_off, int32_t* dirty_rows, int64_t rows_stride, int32_t* report,
+                             void* stream);
+/* per-environment merge plans -> the flat CSR tables of d3d_group_stats7 / d3d_gather_fts; groups past the real ones are empty and
+ * point nowhere (grp_inst -1); totals [2 + B] = groups, tokens, token base per env */
+int32_t d3d_ffdev_flatten_merge(int32_t B, int32_t n_max, const int32_t* slot, const int32_t* dirty_inst, const int32_t* dirty_off,
+                                const int32_t* dirty_rows, int64_t rows_stride, const int32_t* report, int32_t* tok_slot,
+                                int32_t* tok_row, int64_t tok_cap, int32_t* grp_off, int32_t* grp_slot, int32_t* grp_inst,
+                                int32_t* totals, void* stream);
+/* VLN-FF:694-756 for one view.  merged_cells [groups][3]: d3d_group_stats7's cells over the flattened merge groups. */
+int32_t d3d_ffdev_plan_zones(const d3d_ffdev_state* st, const int32_t* slot, int32_t B, const int32_t* dirty_inst,
+                             const int32_t* merged_cells, const int32_t* new_cells, const int32_t* n_seg, int32_t n_max,
+                             int32_t* zone_row, int32_t* zone_mode, int32_t* zone_off, int32_t* zone_mem, int64_t mem_stride,
+                             int32_t* report, void* stream);
+int32_t d3d_ffdev_flatten_zones(int32_t B, int32_t n_max, const int32_t* slot, const int32_t* zone_row, const int32_t* zone_mode,
+                                const int32_t* zone_off, const int32_t* zone_mem, int64_t mem_stride, const int32_t* report,
+                                int32_t* tok_slot, int32_t* tok_inst, int64_t tok_cap, int32_t* grp_off, int32_t* grp_mode,
+                                int32_t* grp_slot, int32_t* grp_row, int32_t* totals, void* stream);
+/* dict-ordered live ids (VLN-FF:825, 844): inst_ids / zone_ids [B][max_ids], counts [B] */
+int32_t d3d_ffdev_live_ids(const d3d_ffdev_state* st, const int32_t* slot, int32_t B, int32_t* inst_ids, int32_t* n_inst,
+                           int32_t* zone_ids, int32_t* n_zone, int32_t max_ids, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from dynam3d_amd.build import build_host_state
+from dynam3d_amd.ff_plan import FFDevOps
 from dynam3d_amd.ops import FTS, CameraTables, Pools
 from oracle import geometry as G
 
@@ -29,11 +30,18 @@ def _np(t):
     return t.numpy() if isinstance(t, torch.Tensor) else t
 
 
-class CpuOps:
+class CpuOps(FFDevOps):
+    """(FFDevOps: the device planner's d3d_ffdev_* entry points -- here the SAME source, csrc/ff_plan.h, compiled over host arrays into
+    the CPU-only test library.)"""
     name = "cpu-emulation"
 
     def __init__(self):
         self.lib = C.CDLL(build_host_state())
+        self.lib.d3d_last_error.restype = C.c_char_p
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"libd3d_ffstate_host: {self.lib.d3d_last_error().decode()} (code {rc})")
 
     # a1 / a2
     def preprocess_depth(self, depth, lo=0.0, hi=10.0):
@@ -215,7 +223,8 @@ class CpuOps:
 
     def scatter_rows(self, pool, slot, row, src, src_row=None):
         s = src if src_row is None else src[src_row.long()]
-        pool[slot.long(), row.long()] = s
+        ok = row >= 0                                       # row -1 = nothing to store (device-planned scatters)
+        pool[slot.long()[ok], row.long()[ok]] = s[ok]
 
     def fill_rows(self, pool, slot, row, value):
         pool[slot.long(), row.long()] = value

@@ -9,23 +9,23 @@ from tests.golden_io import TRAJ_CASES, load, traj_inputs
 from tests.test_oracle_golden import check_env_against_golden
 
 
-def run_case(name, ops, device, on_step=None, max_steps=None, m_cap=4096, z_cap=2048):
+def run_case(name, ops, device, on_step=None, max_steps=None, m_cap=4096, z_cap=2048, planner=None):
     """max_steps: row-pool capacity in steps (default: the whole trajectory fits); smaller values make the pools GROW mid-episode."""
     from dynam3d_amd.f32_ops import F32Ops
     check_before, F32Ops.CHECK = F32Ops.CHECK, str(device) != "cpu"      # every split-precision float32 GEMM output verified finite (f32_ops.py)
     try:
-        return _run_case(name, ops, device, on_step, max_steps, m_cap, z_cap)
+        return _run_case(name, ops, device, on_step, max_steps, m_cap, z_cap, planner)
     finally:
         F32Ops.CHECK = check_before
 
 
-def _run_case(name, ops, device, on_step, max_steps, m_cap, z_cap):
+def _run_case(name, ops, device, on_step, max_steps, m_cap, z_cap, planner):
     case = TRAJ_CASES[name]
     g = load(f"g4_{name}.npz")
     sd = synth_state_dict(ff_param_spec(), seed=0)
     ff = Feature_Fields(case["B"], device=device, state_dict=sd, ops=ops,
                         max_steps=max_steps or (case["steps"] + 1) * case.get("views", 1), variant=case.get("variant", "vln"),
-                        m_cap=m_cap, z_cap=z_cap)
+                        m_cap=m_cap, z_cap=z_cap, planner=planner)
     ff.initialize_camera_setting(90.0, 90.0)
     V, vid = case.get("views", 1), case.get("view_ids")           # view_ids = the Pretrain class's keyword (PRE-FF:674,843)
     for t, inp in enumerate(traj_inputs(case)):
