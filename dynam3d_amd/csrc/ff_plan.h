@@ -465,25 +465,31 @@ FFP_HD void live_ids(Cx& cx, const View& v, int32_t* inst_ids, int32_t* n_inst, 
 template <class Cx>
 FFP_HD void flatten_merge(Cx& cx, int B, int n_max, const int32_t* slot, const int32_t* dirty_inst, const int32_t* dirty_off,
                           const int32_t* dirty_rows, int64_t rows_stride, const int32_t* vh, int32_t* tok_slot, int32_t* tok_row, int64_t tok_cap,
-                          int32_t* grp_off, int32_t* grp_slot, int32_t* grp_inst, int32_t* totals /* [2 + B]: groups, tokens, token base per env */) {
+                          int32_t* grp_off, int32_t* grp_slot, int32_t* grp_inst, int32_t* totals /* [2 + 2B]: groups, tokens, token base / group base per env */) {
     const int G_ub = B * n_max;
     cx.one([&] {
         int g = 0, tot = 0;
         for (int e = 0; e < B; ++e) {
             const int nd = vh[e * V_WORDS + V_NDIRTY];
             totals[2 + e] = tot;
-            for (int d = 0; d < nd; ++d) {
-                grp_off[g] = tot + dirty_off[e * (n_max + 1) + d];
-                grp_slot[g] = slot[e];
-                grp_inst[g] = dirty_inst[e * n_max + d];
-                ++g;
-            }
+            totals[2 + B + e] = g;
+            g += nd;
             tot += dirty_off[e * (n_max + 1) + nd];
         }
         totals[0] = g;
         totals[1] = tot;
-        for (; g < G_ub; ++g) { grp_off[g] = tot; grp_slot[g] = 0; grp_inst[g] = -1; }
-        grp_off[G_ub] = tot;
+    });
+    const int n_groups = totals[0], total = totals[1];
+    cx.par(G_ub, [&](int i) {                                      // (environment, d-th merged instance) -> its flat group
+        const int e = i / n_max, d = i % n_max;
+        if (d < vh[e * V_WORDS + V_NDIRTY]) {
+            const int g = totals[2 + B + e] + d;
+            grp_off[g] = totals[2 + e] + dirty_off[e * (n_max + 1) + d];
+            grp_slot[g] = slot[e];
+            grp_inst[g] = dirty_inst[e * n_max + d];
+        }
+        if (i >= n_groups) { grp_off[i] = total; grp_slot[i] = 0; grp_inst[i] = -1; }
+        if (i == 0) grp_off[G_ub] = total;
     });
     for (int e = 0; e < B; ++e) {
         const int nd = vh[e * V_WORDS + V_NDIRTY];
@@ -507,19 +513,25 @@ FFP_HD void flatten_zones(Cx& cx, int B, int n_max, const int32_t* slot, const i
         for (int e = 0; e < B; ++e) {
             const int nt = vh[e * V_WORDS + V_NTOUCHED];
             totals[2 + e] = tot;
-            for (int t = 0; t < nt; ++t) {
-                grp_off[g] = tot + zone_off[e * (n_max + 1) + t];
-                grp_mode[g] = zone_mode[e * n_max + t];
-                grp_slot[g] = slot[e];
-                grp_row[g] = zone_row[e * n_max + t];
-                ++g;
-            }
+            totals[2 + B + e] = g;
+            g += nt;
             tot += zone_off[e * (n_max + 1) + nt];
         }
         totals[0] = g;
         totals[1] = tot;
-        for (; g < G_ub; ++g) { grp_off[g] = tot; grp_mode[g] = 0; grp_slot[g] = 0; grp_row[g] = 0; }
-        grp_off[G_ub] = tot;
+    });
+    const int n_groups = totals[0], total = totals[1];
+    cx.par(G_ub, [&](int i) {
+        const int e = i / n_max, t = i % n_max;
+        if (t < vh[e * V_WORDS + V_NTOUCHED]) {
+            const int g = totals[2 + B + e] + t;
+            grp_off[g] = totals[2 + e] + zone_off[e * (n_max + 1) + t];
+            grp_mode[g] = zone_mode[e * n_max + t];
+            grp_slot[g] = slot[e];
+            grp_row[g] = zone_row[e * n_max + t];
+        }
+        if (i >= n_groups) { grp_off[i] = total; grp_mode[i] = 0; grp_slot[i] = 0; grp_row[i] = 0; }
+        if (i == 0) grp_off[G_ub] = total;
     });
     for (int e = 0; e < B; ++e) {
         const int nt = vh[e * V_WORDS + V_NTOUCHED];

@@ -14,7 +14,7 @@
 namespace {
 
 using namespace ffplan;
-constexpr int PLAN_BLOCK = 512;
+constexpr int PLAN_BLOCK = 1024;
 constexpr int PLAN_WAVES = PLAN_BLOCK / 64;
 
 struct BlockCtx {

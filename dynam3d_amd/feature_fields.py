@@ -599,10 +599,11 @@ class Feature_Fields(RefreshOnChange):
         G_ub = B * n_max
         rows_stride = max(rb) + P
         # one int32 block for everything the host reads back: report words | totals (merge) | totals (zones) | group offsets x 2
-        rep = torch.zeros((B * REPORT_WORDS + 2 * (2 + B) + 2 * (G_ub + 1),), dtype=torch.int32, device=self.device)
+        nt_ = 2 + 2 * B
+        rep = torch.zeros((B * REPORT_WORDS + 2 * nt_ + 2 * (G_ub + 1),), dtype=torch.int32, device=self.device)
         o = B * REPORT_WORDS
-        report, tot_m, tot_z = rep[:o], rep[o:o + 2 + B], rep[o + 2 + B:o + 2 * (2 + B)]
-        o += 2 * (2 + B)
+        report, tot_m, tot_z = rep[:o], rep[o:o + nt_], rep[o + nt_:o + 2 * nt_]
+        o += 2 * nt_
         goff, zgoff = rep[o:o + G_ub + 1], rep[o + G_ub + 1:]
         seg_slot, dirty_inst, dirty_off, dirty_rows = ops.ffdev_plan_merge(st, slot, order_d, tok_seg_d, seg_off_d, n_seg_d, n_max, k_max, k0_d, d2, idx, logits,
                                                                            cell, rows_stride, report)
@@ -619,8 +620,8 @@ class Feature_Fields(RefreshOnChange):
         o = B * REPORT_WORDS
         st.take_report_envs(envs, rep_h[:o].reshape(B, REPORT_WORDS))
         n_m, T_m = int(rep_h[o]), int(rep_h[o + 1])
-        n_z, T_z = int(rep_h[o + 2 + B]), int(rep_h[o + 2 + B + 1])
-        o += 2 * (2 + B)
+        n_z, T_z = int(rep_h[o + nt_]), int(rep_h[o + nt_ + 1])
+        o += 2 * nt_
         goff_h, zgoff_h = rep_h[o:o + G_ub + 1], rep_h[o + G_ub + 1:]
         if n_m:                                                                                      # VLN-FF:662-688
             mfts = ops.gather_fts(pools, ts[:T_m], tr[:T_m])
@@ -658,7 +659,8 @@ class Feature_Fields(RefreshOnChange):
                     pad[e, :n_ids[e]] = ids[e][which]
                 rel, fts, kept, count = self.ops.agent_frame_compact(pp, pf, slot, self._i32(pad), self._i32(n_ids), pose, float(radius))
                 out[key] = (rel, fts, kept, count)
-        ci, cz = out["instance"][3].cpu().numpy(), out["zone"][3].cpu().numpy()      # sync #4: Ni, Nz
+        cc = torch.stack([out["instance"][3], out["zone"][3]]).cpu().numpy()          # sync #4: Ni, Nz (one read)
+        ci, cz = cc[0], cc[1]
         return {
             "batch_instance_fts": [out["instance"][1][e, :ci[e]] for e in envs],
             "batch_instance_relative_position": [out["instance"][0][e, :ci[e]] for e in envs],

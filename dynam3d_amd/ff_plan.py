@@ -85,7 +85,7 @@ class FFDevOps:
         B, dev = slot.shape[0], slot.device
         seg_slot = torch.empty((B, n_max), dtype=torch.int32, device=dev)
         dirty_inst = torch.empty((B, n_max), dtype=torch.int32, device=dev)
-        dirty_off = torch.zeros((B, n_max + 1), dtype=torch.int32, device=dev)
+        dirty_off = torch.empty((B, n_max + 1), dtype=torch.int32, device=dev)
         dirty_rows = torch.empty((B, rows_stride), dtype=torch.int32, device=dev)
         self._ck(self._ffdev().d3d_ffdev_plan_merge(st.struct(), _p(slot), B, _p(order), _p(tok_seg), _p(seg_off), _p(n_seg), n_max, k_max, _p(k0), _p(d2), _p(idx),
                                                     _p(logits), _p(new_cells), _p(seg_slot), _p(dirty_inst), _p(dirty_off), _p(dirty_rows), rows_stride, _p(report),
@@ -107,7 +107,7 @@ class FFDevOps:
         B, dev = slot.shape[0], slot.device
         zone_row = torch.empty((B, n_max), dtype=torch.int32, device=dev)
         zone_mode = torch.empty((B, n_max), dtype=torch.int32, device=dev)
-        zone_off = torch.zeros((B, n_max + 1), dtype=torch.int32, device=dev)
+        zone_off = torch.empty((B, n_max + 1), dtype=torch.int32, device=dev)
         zone_mem = torch.empty((B, mem_stride), dtype=torch.int32, device=dev)
         self._ck(self._ffdev().d3d_ffdev_plan_zones(st.struct(), _p(slot), B, _p(dirty_inst), _p(merged_cells), _p(new_cells), _p(n_seg), n_max, _p(zone_row),
                                                     _p(zone_mode), _p(zone_off), _p(zone_mem), mem_stride, _p(report), self._ffdev_stream()))
@@ -128,10 +128,10 @@ class FFDevOps:
 
     def ffdev_live_ids(self, st: "DevicePlanner", slot, max_ids: int):
         B, dev = slot.shape[0], slot.device
-        inst_ids = torch.zeros((B, max_ids), dtype=torch.int32, device=dev)
-        zone_ids = torch.zeros((B, max_ids), dtype=torch.int32, device=dev)
-        n_inst = torch.zeros((B,), dtype=torch.int32, device=dev)
-        n_zone = torch.zeros((B,), dtype=torch.int32, device=dev)
+        inst_ids = torch.empty((B, max_ids), dtype=torch.int32, device=dev)
+        zone_ids = torch.empty((B, max_ids), dtype=torch.int32, device=dev)
+        n_inst = torch.empty((B,), dtype=torch.int32, device=dev)
+        n_zone = torch.empty((B,), dtype=torch.int32, device=dev)
         self._ck(self._ffdev().d3d_ffdev_live_ids(st.struct(), _p(slot), B, _p(inst_ids), _p(n_inst), _p(zone_ids), _p(n_zone), max_ids, self._ffdev_stream()))
         return inst_ids, n_inst, zone_ids, n_zone
 

@@ -548,7 +548,7 @@ int32_t d3d_ffdev_plan_merge(const d3d_ffdev_state* st, const int32_t* slot, int
                              int32_t* dirty_inst, int32_t* dirty_off, int32_t* dirty_rows, int64_t rows_stride, int32_t* report,
                              void* stream);
 /* per-environment merge plans -> the flat CSR tables of d3d_group_stats7 / d3d_gather_fts; groups past the real ones are empty and
- * point nowhere (grp_inst -1); totals [2 + B] = groups, tokens, token base per env */
+ * point nowhere (grp_inst -1); totals [2 + 2B] = groups, tokens, token base per env, group base per env */
 int32_t d3d_ffdev_flatten_merge(int32_t B, int32_t n_max, const int32_t* slot, const int32_t* dirty_inst, const int32_t* dirty_off,
                                 const int32_t* dirty_rows, int64_t rows_stride, const int32_t* report, int32_t* tok_slot,
                                 int32_t* tok_row, int64_t tok_cap, int32_t* grp_off, int32_t* grp_slot, int32_t* grp_inst,

@@ -121,7 +121,7 @@ def run_random(ops, host_lib: C.CDLL, device, compat: str, seed: int, B: int = 2
                                                                            _t(idx, device), _t(logits, device, torch.float32), cells_d, rows_stride, rep)
         G_ub = B * n_max
         goff = torch.zeros((G_ub + 1,), dtype=torch.int32, device=device)
-        tot = torch.zeros((2 + B,), dtype=torch.int32, device=device)
+        tot = torch.zeros((2 + 2 * B,), dtype=torch.int32, device=device)
         ts, tr, gs, gi = ops.ffdev_flatten_merge(slot, n_max, dirty_inst, dirty_off, dirty_rows, rep, goff, tot)
         rep_h = rep.cpu().numpy().reshape(B, REPORT_WORDS).copy()
         seg_slot_h, dirty_h, doff_h, drows_h = seg_slot.cpu().numpy(), dirty_inst.cpu().numpy(), dirty_off.cpu().numpy(), dirty_rows.cpu().numpy()
@@ -151,7 +151,7 @@ def run_random(ops, host_lib: C.CDLL, device, compat: str, seed: int, B: int = 2
         assert tot_h[0] == g and np.all(gi_h[g:] == -1) and np.all(goff_h[g:] == tot_h[1])
         zone_row, zone_mode, zone_off, zone_mem = ops.ffdev_plan_zones(dev, slot, dirty_inst, _t(merged_cells, device), cells_d, n_seg_d, n_max, M, rep)
         zgoff = torch.zeros((G_ub + 1,), dtype=torch.int32, device=device)
-        ztot = torch.zeros((2 + B,), dtype=torch.int32, device=device)
+        ztot = torch.zeros((2 + 2 * B,), dtype=torch.int32, device=device)
         zts, zti, zmode, zgs, zgr = ops.ffdev_flatten_zones(slot, n_max, zone_row, zone_mode, zone_off, zone_mem, rep, zgoff, ztot)
         rep_h = rep.cpu().numpy().reshape(B, REPORT_WORDS)
         dev.take_report_envs(range(B), rep_h)

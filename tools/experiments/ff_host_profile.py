@@ -5,7 +5,6 @@ import numpy as np, torch
 from dynam3d_amd.feature_fields import Feature_Fields
 from dynam3d_amd.weights import ff_param_spec, synth_state_dict
 from dynam3d_amd.synthetic import SyntheticEpisodes
-from oracle import geometry as G
 
 B = 8
 ff = Feature_Fields(B, "cuda", synth_state_dict(ff_param_spec(), 0), max_steps=20)
@@ -14,8 +13,9 @@ pr = cProfile.Profile()
 import time
 for t in range(14):
     fr = ep.next()
-    dfull = torch.from_numpy(G.preprocess_depth(fr.depth)[..., 0]).cuda().view(B, 1, 224, 224)
-    d24 = torch.from_numpy(G.preprocess_depth(G.downsample_depth_nearest(fr.depth)).reshape(B, 1, 576)).cuda()
+    depth = torch.from_numpy(fr.depth).cuda()[..., 0]
+    dfull = ff.ops.preprocess_depth(depth).view(B, 1, 224, 224)
+    d24 = ff.ops.resize_nearest_preprocess(depth, 24, 24).view(B, 1, 576)
     grid = torch.randn(B, 1, 576, 768, device="cuda").half()
     pos, hd = [p.tolist() for p in fr.positions], list(fr.headings)
     ff.delete_old_features_from_camera_frustum(dfull, pos, hd)
