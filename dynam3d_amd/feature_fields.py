@@ -78,7 +78,8 @@ class Feature_Fields(RefreshOnChange):
         `dynam3d.pth` afterwards, VLN-POL:77-80).
         planner: "device" = the id / dict bookkeeping runs on the GPU next to the float kernels (csrc/ff_plan.h: one small report read
         back per view); "host" = the C++ state machine (csrc/ff_state.cpp: the update waits for the host before every decision; the
-        training branch needs it).  Default: $D3D_FF_PLANNER, else "host"."""
+        training branch needs it).  Default: $D3D_FF_PLANNER, else "device" for the VLN variant (inference only, VLN-POL:150-151) and
+        "host" for the Pretrain variant (whose update also runs with is_training=True)."""
         super().__init__()
         self.device = torch.device(device)
         self.args = _args_namespace()
@@ -105,7 +106,7 @@ class Feature_Fields(RefreshOnChange):
                 install_param(self, k, v.detach().to(self.device, torch.float32).contiguous())
         self._init_refresh_hooks()
         self.refresh()
-        self.planner = planner or os.environ.get("D3D_FF_PLANNER", "host")
+        self.planner = planner or os.environ.get("D3D_FF_PLANNER") or ("device" if variant == "vln" else "host")
         if self.planner not in ("host", "device"):
             raise ValueError("planner must be 'host' or 'device'")
         if self.planner == "device":

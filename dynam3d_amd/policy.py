@@ -160,7 +160,7 @@ class Dynam3D_VLN(RefreshOnChange):
     def __init__(self, cfg: PolicyConfig = PolicyConfig(), weights: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0,
                  device="cuda", batch_size: int = 1, ops=None, tokenizer=None, segmenter=None, max_steps: int = 64,
                  depth_encoder: Optional[torch.nn.Module] = None, ff_planner: Optional[str] = None):
-        """ff_planner: `Feature_Fields(planner=...)` -- "device" / "host" bookkeeping of the 3D memory (default: $D3D_FF_PLANNER, else host)."""
+        """ff_planner: `Feature_Fields(planner=...)` -- "device" / "host" bookkeeping of the 3D memory (default: $D3D_FF_PLANNER, else device)."""
         super().__init__()
         self.cfg, self.device = cfg, torch.device(device)
         if self.device.type == "cuda" and cfg.hip_dense:

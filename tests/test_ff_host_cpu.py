@@ -9,17 +9,17 @@ from tests.golden_io import TRAJ_CASES
 
 @pytest.mark.parametrize("name", list(TRAJ_CASES))
 def test_host_state_machine_matches_golden(name):
-    run_case(name, CpuOps(), "cpu")
+    run_case(name, CpuOps(), "cpu", planner="host")
 
 
 def test_row_pools_grow_mid_episode():
     """Capacity for ONE step of rows: every later step reallocates the row pools (Feature_Fields._grow_rows) and must carry the
     stored rows, tomb-stones and features over unchanged -- the whole 'walk' trajectory still matches the reference golden."""
-    ff = run_case("walk", CpuOps(), "cpu", max_steps=1)
+    ff = run_case("walk", CpuOps(), "cpu", max_steps=1, planner="host")
     assert ff.pools.n_cap >= 7 * 576
 
 
 def test_instance_and_zone_pools_grow():
     """The reference's instance / zone stores are unbounded (torch.cat); tiny initial pools must double their way through the golden."""
-    ff = run_case("walk", CpuOps(), "cpu", m_cap=8, z_cap=2)
+    ff = run_case("walk", CpuOps(), "cpu", m_cap=8, z_cap=2, planner="host")
     assert ff.pools.m_cap > 8 and ff.pools.z_cap > 2

@@ -1,4 +1,4 @@
-"""GPU: the device-resident Feature_Fields (HIP kernels + C++ bookkeeping) replays the reference's golden
+"""GPU: the device-resident Feature_Fields (HIP kernels + the C++ host bookkeeping; tests/test_gpu_ff_plan.py: + the device planner) replays the reference's golden
 trajectories: dict/id bookkeeping and KNN-driven merge decisions exact, positions within float32 rounding
 of the reference's own summation order, features within 1e-3 (relative L2 on the final stores)."""
 import pytest
@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("name", list(TRAJ_CASES))
 def test_feature_fields_trajectory_parity(name):
     from dynam3d_amd.ops import HipOps
-    ff = run_case(name, HipOps(), "cuda")
+    ff = run_case(name, HipOps(), "cuda", planner="host")
     assert ff.pools.rows_fts.is_cuda
 
 
 def test_row_pools_grow_mid_episode():
     """Row pools sized for one step: they are reallocated (and copied on the device) during the episode; golden parity holds."""
     from dynam3d_amd.ops import HipOps
-    ff = run_case("walk", HipOps(), "cuda", max_steps=1, m_cap=8, z_cap=2)       # instance / zone pools double as well
+    ff = run_case("walk", HipOps(), "cuda", max_steps=1, m_cap=8, z_cap=2, planner="host")       # instance / zone pools double as well
     assert ff.pools.n_cap >= 7 * 576 and ff.pools.m_cap > 8 and ff.pools.z_cap > 2
 
 
