@@ -26,6 +26,23 @@ class StepOracle:
         self.depth_scale = depth_scale
         self.timing = {}
 
+    ff_threads = None      # torch intra-op threads for the 3D-memory stage: thousands of set-sized (17 x 768) products per step, which a
+                           # many-core host runs several times SLOWER on all its cores than on 8-16 (fork-join cost per op); None = leave as is
+
+    def _ff_threads(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            n = torch.get_num_threads()
+            if self.ff_threads:
+                torch.set_num_threads(int(self.ff_threads))
+            try:
+                yield
+            finally:
+                torch.set_num_threads(n)
+        return cm()
+
     @torch.no_grad()
     def build_inputs(self, rgb: np.ndarray, depth: np.ndarray, instructions: List[str], positions, headings, patch_segm):
         B = rgb.shape[0]
@@ -35,9 +52,10 @@ class StepOracle:
         _, grid = TR.clip_vit_forward(px, self.sd, self.vit.layers, self.vit.heads, self.vit.patch, lowp=self.clip_lowp)   # VLN-POL:344
         t1 = time.time()
         dfull = G.preprocess_depth(depth, self.depth_scale)[..., 0]
-        self.ff.delete_old_features_from_camera_frustum(dfull.reshape(B, 1, *dfull.shape[1:]), positions, headings)   # VLN-POL:351
-        self.ff.update_feature_fields(d24, grid.numpy().reshape(B, 1, *grid.shape[1:]), patch_segm, positions, headings)  # VLN-POL:354
-        env = self.ff.get_environment_features(positions, headings)
+        with self._ff_threads():
+            self.ff.delete_old_features_from_camera_frustum(dfull.reshape(B, 1, *dfull.shape[1:]), positions, headings)   # VLN-POL:351
+            self.ff.update_feature_fields(d24, grid.numpy().reshape(B, 1, *grid.shape[1:]), patch_segm, positions, headings)  # VLN-POL:354
+            env = self.ff.get_environment_features(positions, headings)
         info = self.ff.get_patch_3d_info(d24.reshape(B, -1))
         rx, ry, rz, dr, sc = (torch.from_numpy(np.ascontiguousarray(a)) for a in info)
         info6 = torch.cat([rx, ry, rz, torch.sin(dr), torch.cos(dr), sc], -1)
@@ -75,8 +93,9 @@ class StepOracle:
         B = depth.shape[0]
         d24 = G.preprocess_depth(G.downsample_depth_nearest(depth), self.depth_scale).reshape(B, 1, -1)
         dfull = G.preprocess_depth(depth, self.depth_scale)[..., 0]
-        self.ff.delete_old_features_from_camera_frustum(dfull.reshape(B, 1, *dfull.shape[1:]), positions, headings)
-        self.ff.update_feature_fields(d24, np.asarray(grid, np.float32).reshape(B, 1, *grid.shape[1:]), patch_segm, positions, headings)
+        with self._ff_threads():
+            self.ff.delete_old_features_from_camera_frustum(dfull.reshape(B, 1, *dfull.shape[1:]), positions, headings)
+            self.ff.update_feature_fields(d24, np.asarray(grid, np.float32).reshape(B, 1, *grid.shape[1:]), patch_segm, positions, headings)
 
     @torch.no_grad()
     def forward_logits(self, rgb, depth, instructions, positions, headings, patch_segm) -> np.ndarray:
