@@ -1,6 +1,7 @@
 #!/bin/bash
 # Per-round profile set: `bash tools/profile_round.sh r04` -> gpurun_out/r04/ (copy the summaries into profiles/ with the round prefix):
-#   1. rocprofv3 kernel trace + stats of the DEFAULT benchmark command; per-kernel summary; one row per timed gate_up launch
+#   1. rocprofv3 kernel trace + stats of the DEFAULT benchmark command (minus the CPU leg and the generation block that follow the timed region);
+#      per-kernel summary; one row per timed gate_up launch
 #   2. three --pmc passes over the dominant GEMM (gate_up, M = 6656: the mean packed rows of the timed steps)
 #   3. --pmc passes over the flash-attention kernel at the Phi-3 packed shape and the ViT shape (VALU vs MFMA busy)
 #   4. kernel trace of the Pretrain render path (tools/bench_render.py)
@@ -10,7 +11,7 @@ round=${1:-r04}
 out=gpurun_out/$round
 rm -rf $out && mkdir -p $out
 # ---- 1. benchmark trace ----------------------------------------------------------------------------------------------------------
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python bench.py --cpu-baseline off > $out/bench_prof.json 2> $out/bench_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python bench.py --cpu-baseline off --no-decode > $out/bench_prof.json 2> $out/bench_prof.err
 f=$(find $out/trace -name "*kernel_trace.csv" | head -1)
 python tools/prof_summary.py "$f" 20 > $out/kernel_summary.txt          # 8 memory-warming + 2 warm-up + 10 timed passes
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
