@@ -174,7 +174,7 @@ FFP_HD void apply_hits(Cx& cx, const View& v, const int32_t* hits, int n_hits, c
 // logits ([n_seg][k_max][2]) and the new segments' zone cells ([n_seg][3]).  Outputs: seg_slot[s] = slot of the NEW instance segment s
 // opens (-1 = merged), the merged ("dirty") instances in first-touch order with their full member lists (CSR), the report words.
 // The reference walks the segments one after the other; here only the ranks are sequential (ordered compactions), the rest is a sweep.
-// scratch use: new_pid [P] | seg_inst [P] | new_inst [P] | new_rank [P] | misc.
+// scratch use: new_pid [P] | seg_inst [P] | new_inst [P] | new_rank [P] | misc [8] | rank_seg [P].
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <class Cx>
 FFP_HD void plan_merge(Cx& cx, const View& v, int compat_fixed, int P, const int32_t* order, const int32_t* tok_seg, const int32_t* seg_off,
@@ -185,6 +185,7 @@ FFP_HD void plan_merge(Cx& cx, const View& v, int compat_fixed, int P, const int
     int32_t* new_inst = v.scratch + 2 * (int64_t)P;
     int32_t* new_rank = v.scratch + 3 * (int64_t)P;
     int32_t* misc = v.scratch + 4 * (int64_t)P;                   // [0] k_eff  [1] error bits
+    int32_t* rank_seg = v.scratch + 4 * (int64_t)P + 8;           // segment that opens the c-th new instance
     cx.sync();
     const int row_base = v.hdr[H_NROWS];
     const int ns0 = v.hdr[H_NSLOTS];
@@ -216,7 +217,7 @@ FFP_HD void plan_merge(Cx& cx, const View& v, int compat_fixed, int P, const int
         }
         seg_slot[q] = fp;
     });
-    const int n_new = cx.compact(n_seg, NO_LIMIT, [&](int q) { return seg_slot[q] < 0; }, [&](int q, int c) { new_rank[q] = c; });
+    const int n_new = cx.compact(n_seg, NO_LIMIT, [&](int q) { return seg_slot[q] < 0; }, [&](int q, int c) { new_rank[q] = c; rank_seg[c] = q; });
     // lowest unused instance ids / patch ids (VLN-FF:433-475)
     cx.compact(ns0 + n_new, n_new, [&](int i) { return !(i < ns0 && v.live[i] != 0); }, [&](int i, int c) { new_inst[c] = i; });
     if (compat_fixed) {
@@ -224,6 +225,7 @@ FFP_HD void plan_merge(Cx& cx, const View& v, int compat_fixed, int P, const int
     } else {
         cx.compact(row_base + P, P, [&](int i) { return v.owner[i] < 0; }, [&](int i, int c) { new_pid[c] = i; });
     }
+    cx.par(n_new, [&](int c) { if (new_inst[c] < v.M) v.icnt[new_inst[c]] = 0; });   // (counts below are accumulated: a merge may target a slot opened in this view)
     cx.sync();
     const int stamp0 = v.hdr[H_STAMP];
     cx.par(n_seg, [&](int s) {
@@ -234,13 +236,23 @@ FFP_HD void plan_merge(Cx& cx, const View& v, int compat_fixed, int P, const int
             v.live[inst] = 1;
             v.istamp[inst] = stamp0 + c + 1;
             v.icx[inst] = new_cells[s * 3]; v.icy[inst] = new_cells[s * 3 + 1]; v.icz[inst] = new_cells[s * 3 + 2];
-            v.icnt[inst] = cnt;
+            cx.atomic_add(&v.icnt[inst], cnt);
             seg_slot[s] = inst;
             seg_inst[s] = inst;
         } else {                                                   // merge into the first positive proposal only (VLN-FF:651-691)
             const int inst = idx[(int64_t)s * k_max + seg_slot[s]];
             seg_slot[s] = -1;
-            if (inst < 0 || inst >= ns0 || !v.live[inst]) { cx.atomic_or(&misc[1], ERR_PROPOSAL_NOT_LIVE); seg_inst[s] = -1; return; }   // KeyError in the reference
+            // Is the proposed slot a key of the instance dict WHEN THE REFERENCE REACHES SEGMENT s?  The reference walks the segments in
+            // order, so a dead slot recycled in this very view exists for the segments behind the one that opens it and is a KeyError for
+            // the ones in front.  live[] of such a slot is being written by the branch above in this same sweep: it is decided from the
+            // (ascending) list of recycled slots and the opening segment's index instead, never by reading live[] of a recycled slot.
+            bool ok = inst >= 0 && inst < ns0;
+            if (ok) {
+                int lo = 0, hi = n_new;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (new_inst[mid] < inst) lo = mid + 1; else hi = mid; }
+                ok = (lo < n_new && new_inst[lo] == inst) ? (rank_seg[lo] < s) : (v.live[inst] != 0);
+            }
+            if (!ok) { cx.atomic_or(&misc[1], ERR_PROPOSAL_NOT_LIVE); seg_inst[s] = -1; return; }   // KeyError in the reference
             seg_inst[s] = inst;
             cx.atomic_add(&v.icnt[inst], cnt);
         }

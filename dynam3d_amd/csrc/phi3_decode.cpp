@@ -26,9 +26,10 @@ extern "C" int32_t d3d_phi3_decode_token(const d3d_phi3_decode_args* a) {
     // History (tools/bench_decode.py, ms per token against 3.46-3.50 unfused): normalising every activation fragment inside the K loop 3.76
     // (round 2); the rows normalised once per workgroup into LDS 3.67 (the extra 49 KB pushed the 16-wave workgroups to one per CU);
     // with that buffer overlaid on the wave-reduction buffer (two per CU again) 3.38 -- the default since round 4.  D3D_DECODE_FUSE_NORM=0
-    // selects the seven-launch layer.
+    // selects the seven-launch layer.  Rows 9-16 need twice the LDS for the normalised rows (98 KB at K = 3072): one workgroup per CU
+    // again, the regime measured SLOWER than the seven-launch layer -- they take the seven launches.
     const char* fe = getenv("D3D_DECODE_FUSE_NORM");
-    const bool fuse = !(fe && fe[0] == '0') && Hd % 512 == 0 && qkv_w % 32 == 0 && (2 * I) % 32 == 0;
+    const bool fuse = !(fe && fe[0] == '0') && B <= 8 && Hd % 512 == 0 && qkv_w % 32 == 0 && (2 * I) % 32 == 0;
     void* s = a->stream;
     void* x = a->x;                       // (rows, hidden) in / out: the residual stream
     int32_t rc;

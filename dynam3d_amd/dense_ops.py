@@ -20,11 +20,13 @@ _hip = None  # set by enable_hip_kernels()
 
 # ---- strict mode + dispatch accounting ---------------------------------------------------------------------------
 # Every primitive below either launches a hand-written kernel ("hip") or -- when a shape / dtype predicate fails, or on
-# the CPU -- runs the PyTorch expression next to it.  On a GPU that second branch is a silent change of backend, so it is
-# counted per primitive, and under STRICT it raises instead: bench.py, smoke() and the GPU tower tests run strict, and the
-# benchmark line prints both tables (`fallbacks` must be empty).  CPU tensors are never counted: the CPU suite drives the
-# host logic through these expressions by design.
-STRICT = False
+# the CPU -- runs the PyTorch expression next to it.  On a GPU that second branch would be a silent change of backend
+# (hipBLASLt / SDPA instead of the product's kernels), so STRICT IS THE DEFAULT: a CUDA tensor that cannot take the HIP
+# kernel RAISES.  The PyTorch expressions stay for CPU tensors (the CPU suite drives the host logic through them by design;
+# never counted) and for callers that opt out explicitly -- `strict(False)` / `with allow_fallback():` (A/B baselines of
+# bench.py --hip-dense, toy configurations below the kernels' tile sizes in tests); opted-out calls are counted per primitive
+# and the benchmark line prints both tables (`fallbacks` must be empty).
+STRICT = True
 COUNTS = {"hip": {}, "fallback": {}}
 
 
@@ -36,6 +38,20 @@ def strict(on: bool = True):
     """Raise `DenseFallbackError` whenever a CUDA tensor would take a PyTorch expression instead of a HIP kernel."""
     global STRICT
     STRICT = bool(on)
+
+
+class allow_fallback:
+    """`with allow_fallback():` -- the explicit opt-out of strict mode for a block (restores the previous mode)."""
+
+    def __enter__(self):
+        global STRICT
+        self.was, STRICT = STRICT, False
+        return self
+
+    def __exit__(self, *exc):
+        global STRICT
+        STRICT = self.was
+        return False
 
 
 def reset_counts():
@@ -56,7 +72,8 @@ def _miss(prim: str, t: torch.Tensor, why: str):
         return
     COUNTS["fallback"][prim] = COUNTS["fallback"].get(prim, 0) + 1
     if STRICT:
-        raise DenseFallbackError(f"dense_ops.{prim}: no HIP kernel for this call ({why}); strict mode forbids the PyTorch expression")
+        raise DenseFallbackError(f"dense_ops.{prim}: no HIP kernel for this call on a CUDA tensor ({why}); the PyTorch expression is a different "
+                                 f"backend and is not taken silently -- opt out with dense_ops.strict(False) / `with dense_ops.allow_fallback():`")
 
 
 def enable_hip_kernels(which: Sequence[str] = ("all",)):

@@ -17,6 +17,13 @@ from typing import Dict, Optional
 import torch
 import torch.distributed as dist
 
+def _active() -> bool:
+    """Collectives are issued when a process group exists and it has more than one rank -- or, with `D3D_DIST_FORCE=1`, even at
+    world size 1: the single-rank collective is an identity, but it runs the whole backend path (communicator creation, device
+    buffers, stream ordering), which is how the one-GPU test box exercises RCCL (tests/test_gpu_rccl.py)."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("D3D_DIST_FORCE") == "1")
+
+
 METRIC_KEYS = ("steps_taken", "distance_to_goal", "success", "oracle_success", "path_length", "collisions", "spl", "ndtw", "sdtw")
 
 
@@ -26,7 +33,7 @@ def init_from_env(backend: Optional[str] = None):
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("D3D_SHARE_DEVICE0") == "1":
         local = 0          # test hook: several ranks on ONE GPU (with D3D_DIST_BACKEND=gloo; RCCL refuses duplicate devices)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("D3D_DIST_FORCE") == "1") and not dist.is_initialized():
         backend = backend or os.environ.get("D3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
@@ -34,12 +41,49 @@ def init_from_env(backend: Optional[str] = None):
     return rank, local, world
 
 
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_guard(gpus: int, script: str, argv):
+    """`--gpus N` must mean N ranks on N distinct GPUs, or no number at all (shared by bench.py and rollout.py).
+      * N > 1 without a launcher (WORLD_SIZE unset): re-launch `script argv` under `torch.distributed.run` with N ranks -- if the
+        box has N GPUs; otherwise exit non-zero (a plain `--gpus 8` on one GPU must not print 8x one GPU's rate);
+      * under a launcher whose WORLD_SIZE differs from --gpus: exit non-zero.
+    Runs before anything is allocated."""
+    import subprocess
+    import sys
+    name = os.path.basename(script)
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != gpus:
+            sys.exit(f"{name}: --gpus {gpus} but the launcher started WORLD_SIZE={world_env} ranks; refusing to report a number for a job that is not the one named")
+        return
+    if gpus == 1:
+        return
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get("D3D_SHARE_DEVICE0") == "1":
+        n_dev = max(n_dev, gpus if n_dev >= 1 else 0)          # test hook: several ranks on cuda:0 (see init_from_env)
+    if n_dev < gpus:
+        sys.exit(f"{name}: --gpus {gpus} needs {gpus} GPUs, this machine shows {n_dev}; refusing to report a {gpus}-GPU number "
+                 f"(launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node {gpus} --master-addr 127.0.0.1 --master-port P {name} --gpus {gpus} ...)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port())] + ([script] if not script.startswith("-m ") else ["-m", script[3:]]) + list(argv)
+    print("%s: --gpus %d without a launcher -> %s" % (name, gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd))
+
+
 def gather_metrics(sums: Dict[str, float], n_episodes: int, device="cpu") -> Dict[str, float]:
     """One collective: all_gather of [9 metric sums, count] -> global means (every rank gets the result)."""
     if dist.is_initialized() and dist.get_backend() == "gloo":
         device = "cpu"                      # gloo gathers host tensors (RCCL / "nccl" takes the device tensor)
     v = torch.tensor([float(sums.get(k, 0.0)) for k in METRIC_KEYS] + [float(n_episodes)], dtype=torch.float32, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         out = [torch.empty_like(v) for _ in range(dist.get_world_size())]
         dist.all_gather(out, v)
         tot = torch.stack(out).sum(0)
@@ -53,7 +97,7 @@ def gather_metrics(sums: Dict[str, float], n_episodes: int, device="cpu") -> Dic
 
 def gather_objects(obj):
     """Small per-rank records (device identity, own timing) of every rank, on every rank, in rank order."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         out = [None] * dist.get_world_size()
         dist.all_gather_object(out, obj)
         return out
@@ -61,7 +105,9 @@ def gather_objects(obj):
 
 
 def max_over_ranks(x: float, device="cpu") -> float:
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
+        if dist.get_backend() == "gloo":
+            device = "cpu"
         t = torch.tensor([x], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0])
@@ -69,7 +115,7 @@ def max_over_ranks(x: float, device="cpu") -> float:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         if dist.get_backend() == "nccl":
             dist.barrier(device_ids=[torch.cuda.current_device()])      # pin the collective to this rank's GPU
         else:
@@ -78,7 +124,9 @@ def barrier():
 
 def broadcast_int(value: int, src: int = 0, device="cpu") -> int:
     """PRE-TR:2239-2244: every rank runs the dataset loop rank `src` drew."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
+        if dist.get_backend() == "gloo":
+            device = "cpu"
         t = torch.tensor([int(value)], dtype=torch.int64, device=device)
         dist.broadcast(t, src=src)
         return int(t[0])
@@ -88,7 +136,7 @@ def broadcast_int(value: int, src: int = 0, device="cpu") -> int:
 def any_nan_vote(loss: torch.Tensor) -> bool:
     """PRE-TR:505-509: SUM all-reduce of the loss value; True = some rank produced NaN -> every rank skips backward / the step."""
     v = loss.detach().clone().float().reshape(1)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
     return bool(torch.isnan(v).any())
 
@@ -108,7 +156,8 @@ def all_reduce_gradients(params, bucket_bytes: int = 64 << 20, average: bool = T
     world = dist.get_world_size() if dist.is_initialized() else 1
     has = None
     n_coll = 0
-    if params and world > 1 and not assume_uniform:
+    active = _active()
+    if params and active and not assume_uniform:
         has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=params[0].device)
         dist.all_reduce(has, op=dist.ReduceOp.SUM)
         n_coll += 1
@@ -135,7 +184,7 @@ def all_reduce_gradients(params, bucket_bytes: int = 64 << 20, average: bool = T
             else:
                 flat[o:o + n].copy_(p.grad.reshape(-1))
             o += n
-        if world > 1:
+        if active:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             n_coll += 1
             if average:

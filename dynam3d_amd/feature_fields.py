@@ -30,7 +30,7 @@ from .ops import pinhole_unproject_rows, pinhole_views, FTS, CameraTables, Pools
 from ._ffstate import FFState
 from .ff_plan import REPORT_WORDS, DevicePlanner
 from .ff_dense import FFDense
-from .modules import RefreshOnChange, install_param
+from .modules import RefreshOnChange, install_param, own_copy
 
 RENDER_PREFIXES = ("nerf_", "patch_to_nerf_", "aggregate_patch_to_nerf_")          # Pretrain-only renderer parameters (PRE-FF:221-254)
 IGNORED_PREFIXES = ("FastSAM", "freezed_", "clip_")                                 # sub-networks / frozen copies the memory update never reads
@@ -103,7 +103,7 @@ class Feature_Fields(RefreshOnChange):
             state_dict = synth_state_dict(ff_param_spec(int(self.args.fts_dim)), seed)
         for k, v in state_dict.items():
             if not k.startswith(IGNORED_PREFIXES):
-                install_param(self, k, v.detach().to(self.device, torch.float32).contiguous())
+                install_param(self, k, own_copy(v, self.device, torch.float32))
         self._init_refresh_hooks()
         self.refresh()
         self.planner = planner or os.environ.get("D3D_FF_PLANNER") or ("device" if variant == "vln" else "host")
@@ -134,7 +134,7 @@ class Feature_Fields(RefreshOnChange):
         own = set(dict(self.named_parameters()))
         for k, v in sd.items():
             if k.startswith(RENDER_PREFIXES) and k not in own:
-                install_param(self, k, v.detach().to(self.device, torch.float32).contiguous())
+                install_param(self, k, own_copy(v, self.device, torch.float32))
         return super().load_state_dict(sd, strict=strict, assign=assign)
 
     def refresh(self):
@@ -148,7 +148,16 @@ class Feature_Fields(RefreshOnChange):
         if params:
             dev = next(iter(params.values())).device
             if dev != self.device:
+                # `.to(other_device)` (the trainer's `policy.to(device)`, VLN-TR:183-186): the kernels take raw pointers, so everything
+                # they read must move with the parameters -- pools, planner state, camera tables and the renderer are re-allocated on
+                # the new device.  The 3D memory does not travel (the reference moves the module once, before the first episode).
                 self.device = dev
+                self._cam = None
+                self.pools = None
+                if getattr(self, "state", None) is not None:
+                    if self.planner == "device":
+                        self.state = DevicePlanner(self.compat, self.P, self.args.num_proposal_instances, self.device)
+                    self.reset(self.batch_size)
         flat = {k: p.detach() for k, p in params.items()}
         self._render_sd = {k: v for k, v in flat.items() if k.startswith(RENDER_PREFIXES)}
         self._renderer = None
@@ -188,6 +197,8 @@ class Feature_Fields(RefreshOnChange):
             self.state.reset(batch_size)
             self.state.set_tomb_cell(tomb)
         self.slots: List[int] = list(range(batch_size))
+        if self.planner == "device":
+            self.state.env_slots = self.slots
         self.keep_target_waypoint = [None for _ in range(batch_size)]
         self.history_actions = [["none\n"] * 4 for _ in range(batch_size)]      # per-row lists
         self._tree_slots = [0] * batch_size
@@ -391,6 +402,7 @@ class Feature_Fields(RefreshOnChange):
                 pose = self._poses(batch_position, batch_heading, envs, view_offset=0.0 if view_ids is None else view_ids[ix] * (-math.pi / 6))
                 self.ops.frustum_cull(pools, slot, n_rows_d, mx, d_ix, pose, intr, 0.0, float(a.deleted_frustum_distance), 0.1, hits, n_hits)
             self.ops.ffdev_apply_hits(pl, slot, hits, n_hits, pools)         # VLN-FF:362-393 + the rebuild mark of VLN-FF:396
+            pl.stale = True                                                   # LIVE / ZLIVE / OWNED changed on the device; no report is read here
         self._snapshot_tree()
 
     # ---- a6 contract ------------------------------------------------------------------------------------

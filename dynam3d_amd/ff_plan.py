@@ -174,6 +174,8 @@ class DevicePlanner:
         self.n_zlive: List[int] = [0] * S
         self.n_edges: List[int] = [0] * S
         self.n_owned: List[int] = [0] * S
+        self.stale = False                   # True between a device-side deletion and the next view report (see `count`)
+        self.env_slots = None                # environment -> state slot (the feature field's own list, shared: `pop` keeps it in step)
 
     def pop(self, e: int):
         for a in (self.n_rows, self.n_slots, self.n_live, self.n_zrows, self.n_zids, self.n_zlive, self.n_edges, self.n_owned):
@@ -227,6 +229,12 @@ class DevicePlanner:
     def count(self, e: int, which: int) -> int:
         if which == self.TREE:
             raise NotImplementedError("the tree size lives in the device header: planner.header(slot)[H_TREE_SLOTS]")
+        if self.stale and which in (self.LIVE, self.ZLIVE, self.OWNED):
+            # a frustum deletion (d3d_ffdev_apply_hits) ran since the last view report: it changes these three counters on the device
+            # and reports nothing to the host (no device-to-host read on the step's path) -- a query in between reads the header
+            slot = self.env_slots[e] if self.env_slots is not None else e
+            h = self.header(slot)
+            return int(h[{self.LIVE: H_NLIVE, self.ZLIVE: H_NZLIVE, self.OWNED: H_NOWNED}[which]])
         return int((self.n_rows, self.n_slots, self.n_live, self.n_zrows, self.n_zlive, self.n_owned)[which][e])
 
     def take_report_envs(self, envs, rep: np.ndarray):
@@ -238,6 +246,8 @@ class DevicePlanner:
             r = rep[j]
             self.n_slots[e], self.n_live[e], self.n_zrows[e], self.n_zids[e] = int(r[V_NSLOTS]), int(r[V_NLIVE]), int(r[V_NZROWS]), int(r[V_NZIDS])
             self.n_zlive[e], self.n_edges[e], self.n_owned[e] = int(r[V_NZLIVE]), int(r[V_NEDGES]), int(r[V_NOWNED])
+        if len(envs) == self.batch_size:
+            self.stale = False                                           # every environment's counters are this view's
 
     def header(self, slot: int) -> np.ndarray:
         return self.hdr[slot].cpu().numpy()

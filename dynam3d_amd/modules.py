@@ -44,6 +44,18 @@ class ParamTree(nn.Module):
         raise RuntimeError("ParamTree only holds parameters; the compute objects built from it run the kernels")
 
 
+def own_copy(t: torch.Tensor, device, dtype) -> torch.Tensor:
+    """`t` on `device` in `dtype`, contiguous, in storage the module OWNS: `.to()` / `.contiguous()` return the caller's own tensor when
+    nothing has to change (weights synthesised on the device in the target dtype), and a parameter aliasing the caller's state dict
+    would let `load_state_dict`, an optimizer step or `sync_weights` write through into it and into every sibling model built from the
+    same dict -- cloned in that case."""
+    src = t.detach()
+    out = src.to(device, dtype).contiguous()
+    if out.data_ptr() == src.data_ptr() and out.numel() > 0:
+        out = out.clone()
+    return out
+
+
 def install_param(root: nn.Module, dotted: str, tensor: torch.Tensor, requires_grad: bool = False):
     parts = dotted.split(".")
     mod = root

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import sys
 import time
 
 import numpy as np
@@ -116,6 +117,7 @@ def run_closed_loop(net: Dynam3D_VLN, episodes: int, max_steps: int, seed: int, 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; without a launcher the command re-launches itself under torch.distributed.run (dist.launch_guard)")
     ap.add_argument("--episodes-per-rank", type=int, default=8)
     ap.add_argument("--max-steps", type=int, default=50)
     ap.add_argument("--seed", type=int, default=0)
@@ -125,6 +127,8 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=20, help="max_new_tokens of the generation (VLN-POL:463: 20)")
     ap.add_argument("--grammar-stop-mod", type=int, default=24, help="ActionGrammarTokenizer: ~2 of this many sentences end an episode")
     a = ap.parse_args()
+    if a.gpus is not None:
+        DD.launch_guard(a.gpus, "-m dynam3d_amd.rollout", sys.argv[1:])
     rank, local, world = DD.init_from_env()
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"

@@ -36,11 +36,15 @@ class Frame:
 
 class SyntheticEpisodes:
     def __init__(self, batch_size: int = 8, seed: int = 0, image_hw: int = 224, depth_hw: int = 224,
-                 n_blocks: int = 4, grid: int = 24, stationary: bool = False, wall: float | None = None):
+                 n_blocks: int = 4, grid: int = 24, stationary: bool = False, wall: float | None = None, wall_steps=None):
+        """wall: a flat wall `wall` metres in front of the camera instead of random depth -- on every step, or only on the steps listed
+        in `wall_steps` (long trajectories: random-depth steps grow the memory, a wall step re-observes and deletes a large part of what
+        the frustum holds, so ids are recycled and zone snapshots go stale many times over)."""
         self.B = batch_size
         self.rng = np.random.Generator(np.random.PCG64(seed))
         self.image_hw, self.depth_hw, self.grid, self.n_blocks = image_hw, depth_hw, grid, n_blocks
         self.stationary, self.wall = stationary, wall
+        self.wall_steps = None if wall_steps is None else set(int(t) for t in wall_steps)
         self.pos = [np.array([self.rng.uniform(-2, 2), 0.0, self.rng.uniform(-2, 2)], np.float64) for _ in range(batch_size)]
         self.head = [float(self.rng.uniform(0, 2 * math.pi)) for _ in range(batch_size)]
         self.t = 0
@@ -58,7 +62,7 @@ class SyntheticEpisodes:
     def next(self) -> Frame:
         B, rng = self.B, self.rng
         rgb = rng.integers(0, 256, size=(B, self.image_hw, self.image_hw, 3), dtype=np.uint8)
-        if self.wall is None:
+        if self.wall is None or (self.wall_steps is not None and self.t not in self.wall_steps):
             depth = rng.uniform(0.05, 0.5, size=(B, self.depth_hw, self.depth_hw, 1)).astype(np.float32)
         else:  # flat wall `wall` metres away (x10 scaling) -> every stored patch is re-observed
             depth = np.full((B, self.depth_hw, self.depth_hw, 1), self.wall / 10.0, np.float32)

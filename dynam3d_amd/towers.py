@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from . import dense_ops as D
-from .modules import ParamTree, install_param
+from .modules import ParamTree, install_param, own_copy
 from .profiling import TIMER
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
@@ -584,7 +584,7 @@ class ClipEncoder(nn.Module):
         super().__init__()
         dev = torch.device(device)
         names = [n for n, _ in clip_param_spec(cfg)]
-        self.model = ParamTree({n: sd[n].detach().to(dev, clip_storage_dtype(n, dtype)).contiguous() for n in names})
+        self.model = ParamTree({n: own_copy(sd[n], dev, clip_storage_dtype(n, dtype)) for n in names})
         self.tower = ClipVisionTower(self.flat(), cfg, dtype, dev)
         self._sig = self._signature()
 
@@ -628,7 +628,7 @@ class LlavaModel(nn.Module):
     def __init__(self, sd: Dict[str, torch.Tensor], vit: VitConfig, llm: Phi3Config, dtype=torch.bfloat16, device="cuda"):
         super().__init__()
         dev = torch.device(device)
-        st = lambda n: sd[n].detach().to(dev, dtype).contiguous()
+        st = lambda n: own_copy(sd[n], dev, dtype)
         for n, _ in phi3_param_spec(llm):
             self._add(n, st(n), True)
         for n, _ in llava_vision_param_spec(vit):

@@ -18,7 +18,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import ref_harness as rh  # noqa: E402
-from tests.golden_io import traj_inputs, TRAJ_CASES, pack_ragged  # noqa: E402
+from tests.golden_io import traj_inputs, TRAJ_CASES, pack_ragged, int_hash  # noqa: E402
 from dynam3d_amd.weights import ff_param_spec, synth_state_dict  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -195,22 +195,31 @@ def g4_trajectories():
                               inp["positions"], inp["headings"], num_of_views=V)
             F = ref.F
             out[f"t{t}_B"] = np.int64(B)
+            light = bool(case.get("light")) and t not in case.get("key_steps", ())
             for b in range(B):
                 p = f"t{t}_b{b}_"
                 own = F.global_patch_to_instance_dict[b]
                 ks = np.array(sorted(own.keys()), np.int64)
-                out[p + "owner_ids"] = ks
-                out[p + "owner_inst"] = np.array([own[k] for k in ks.tolist()], np.int64)
                 mem = F.global_instance_to_patch_dict[b]
-                out[p + "inst_order"] = np.array(list(mem.keys()), np.int64)
-                out[p + "inst_members"], out[p + "inst_members_off"] = pack_ragged([mem[k] for k in mem])
                 zm = F.global_zone_to_instance_dict[b]
+                owner_inst = np.array([own[k] for k in ks.tolist()], np.int64)
+                im, imo = pack_ragged([mem[k] for k in mem])
+                zmm, zmo = pack_ragged([zm[k] for k in zm])
+                rows_pos = np.asarray(F.global_patch_position[b]).astype(np.float32)
+                out[p + "inst_order"] = np.array(list(mem.keys()), np.int64)
                 out[p + "zone_order"] = np.array(list(zm.keys()), np.int64)
-                out[p + "zone_members"], out[p + "zone_members_off"] = pack_ragged([zm[k] for k in zm])
+                if light:          # (long trajectories) digests of the large integer tables and of the row store's bits
+                    out[p + "book_hash"] = int_hash(ks, owner_inst, im, imo, zmm, zmo)
+                    out[p + "rows_hash"] = int_hash(rows_pos.view(np.uint32))
+                    out[p + "n_rows"] = np.int64(rows_pos.shape[0])
+                else:
+                    out[p + "owner_ids"], out[p + "owner_inst"] = ks, owner_inst
+                    out[p + "inst_members"], out[p + "inst_members_off"] = im, imo
+                    out[p + "zone_members"], out[p + "zone_members_off"] = zmm, zmo
+                    out[p + "rows_pos"] = rows_pos
                 zk = F.global_zone_key_to_id[b]
                 out[p + "zone_keys"] = np.array(list(zk.keys()), np.float32).reshape(-1, 3)
                 out[p + "zone_key_ids"] = np.array(list(zk.values()), np.int64)
-                out[p + "rows_pos"] = np.asarray(F.global_patch_position[b]).astype(np.float32)
                 ip, iF = F.global_instance_position[b].numpy(), F.global_instance_fts[b].numpy()
                 zp, zF = F.global_zone_position[b].numpy(), F.global_zone_fts[b].numpy()
                 out[p + "ipos"], out[p + "zpos"] = ip.copy(), zp.copy()

@@ -24,7 +24,25 @@ TRAJ_CASES = {
     # looks along heading - view_ids[ix]*pi/6 in BOTH the cull and the unprojection, PRE-FF:696,920), 4 merge proposals.
     "prepano": dict(B=2, steps=3, seed=5, grid_seed=9, stationary=False, wall=None, depth_hw=64, views=4, view_ids=[0, 3, 6, 9],
                     variant="pretrain"),
+    # Long horizon: 32 steps at bench-like state (>= 250 live instances per environment).  Random-depth steps delete what the frustum
+    # re-observes closer (VLN-FF:329-396), the wall steps (a flat wall 2 m ahead) wipe most of the frustum at once: instance ids and
+    # patch ids are recycled (VLN-FF:433-475), zone snapshots go stale and zones die and are re-opened (VLN-FF:694-756) for 30 steps
+    # on top of each other.  `light`: only the key steps keep the large arrays; every step keeps the id orders, positions, row sums
+    # and a hash of the integer bookkeeping.
+    "long": dict(B=2, steps=32, seed=21, grid_seed=22, stationary=False, wall=2.0, wall_steps=(9, 10, 19, 27), depth_hw=64,
+                 light=True, key_steps=(0, 8, 9, 10, 11, 19, 20, 27, 28, 31)),
 }
+
+
+def int_hash(*arrays) -> np.int64:
+    """64-bit digest of a sequence of integer arrays (shape-sensitive): the light form of a bookkeeping comparison."""
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(np.asarray(a, np.int64))
+        h.update(np.asarray(a.shape, np.int64).tobytes())
+        h.update(a.tobytes())
+    return np.frombuffer(h.digest()[:8], np.int64)[0]
 
 
 def traj_inputs(case):
@@ -32,7 +50,7 @@ def traj_inputs(case):
     grid (B,V,576,768), patch_segm (B*V,1,24,24) environment-major, positions, headings."""
     B0, V = case["B"], case.get("views", 1)
     eps = [SyntheticEpisodes(B0, seed=case["seed"] + 100 * v, stationary=case["stationary"], wall=case["wall"],
-                             depth_hw=case["depth_hw"], image_hw=32) for v in range(V)]
+                             depth_hw=case["depth_hw"], image_hw=32, wall_steps=case.get("wall_steps")) for v in range(V)]
     rng = np.random.default_rng(case["grid_seed"])
     alive = list(range(B0))
     for t in range(case["steps"]):

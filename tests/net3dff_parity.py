@@ -20,6 +20,13 @@ def pano_observations(eps):
 
 
 def run_net3dff_vs_oracle(ops, device, cfg, steps=2, B=2, clip_dtype=torch.float32, fts_tol=2e-3):
+    import dataclasses
+    from tests.test_policy_cpu import toy_dense
+    with toy_dense(dataclasses.replace(cfg, clip_dtype=clip_dtype), device):
+        return _run_net3dff_vs_oracle(ops, device, cfg, steps, B, clip_dtype, fts_tol)
+
+
+def _run_net3dff_vs_oracle(ops, device, cfg, steps, B, clip_dtype, fts_tol):
     sd = synth_policy_weights(cfg, seed=0)
     net = Net_3DFF(cfg.vit, sd, device=device, batch_size=B, ops=ops, clip_dtype=clip_dtype, max_steps=steps + 1)
     net.feature_fields.initialize_camera_setting(90.0, 90.0)

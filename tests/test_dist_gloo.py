@@ -106,3 +106,36 @@ def test_bench_refuses_a_multi_gpu_number_it_cannot_measure():
     assert out.returncode != 0 and "refusing" in out.stderr and "{" not in out.stdout
     out = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "WORLD_SIZE=4" in out.stderr and "{" not in out.stdout
+
+
+FORCED_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch
+from dynam3d_amd import dist as D
+rank, local, world = D.init_from_env("gloo")
+import torch.distributed as dist
+sums = {k: float(i + 1) for i, k in enumerate(D.METRIC_KEYS)}
+res = D.gather_metrics(sums, n_episodes=2)
+p = torch.nn.Parameter(torch.ones(3)); p.grad = torch.full((3,), 2.0)
+n = D.all_reduce_gradients([p])
+print("RESULT", json.dumps(dict(init=dist.is_initialized(), active=D._active(), world=world, res=res, mx=D.max_over_ranks(3.0), b=D.broadcast_int(5),
+                                objs=D.gather_objects(dict(r=rank)), n=n, g=p.grad.tolist(), vote=D.any_nan_vote(torch.tensor(float("nan"))))))
+D.barrier(); D.shutdown()
+"""
+
+
+def test_forced_collectives_at_world_1(tmp_path):
+    """`D3D_DIST_FORCE=1`: the process group is created and every collective is ISSUED at world size 1 (identity results) -- the
+    hook tests/test_gpu_rccl.py uses to run the same code on RCCL on the one-GPU box; here over gloo."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    w = tmp_path / "fw.py"
+    w.write_text(FORCED_WORKER)
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), D3D_DIST_FORCE="1")
+    p = subprocess.run([sys.executable, str(w), ROOT], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    o = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][7:])
+    assert o["init"] and o["active"] and o["world"] == 1
+    assert o["res"]["episodes"] == 2.0 and o["mx"] == 3.0 and o["b"] == 5 and o["objs"] == [dict(r=0)]
+    assert o["n"] == 2 and o["g"] == [2.0, 2.0, 2.0] and o["vote"] is True

@@ -105,7 +105,7 @@ def test_full_configuration_step_and_generation_vs_oracle_golden():
         report.append(f"generation: teacher-forced argmax == oracle token at {agree}/{total} decided positions (of {T * B}); free-running tokens equal the "
                       f"oracle's for (n, first near-tie) = {same_prefix} of {T}")
     finally:
-        D.strict(False)
+        D.strict(True)                                              # (the default)
     print("\n".join(report))
     out = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "gpurun_out")
     if os.path.isdir(out):

@@ -91,8 +91,10 @@ def test_rollout_driver_pops_finished_episodes():
     from dynam3d_amd.policy import Dynam3D_VLN, synth_policy_weights
     from dynam3d_amd.rollout import run_rollout
     cfg = dataclasses.replace(SMALL, clip_dtype=torch.float16, llava_dtype=torch.bfloat16)
-    net = Dynam3D_VLN(cfg, synth_policy_weights(cfg, 0), device="cuda", batch_size=3, max_steps=8)
-    sums, n = run_rollout(net, 3, 5, seed=4, stop_token_mod=3)
+    from tests.test_policy_cpu import toy_dense
+    with toy_dense(cfg, "cuda"):
+        net = Dynam3D_VLN(cfg, synth_policy_weights(cfg, 0), device="cuda", batch_size=3, max_steps=8)
+        sums, n = run_rollout(net, 3, 5, seed=4, stop_token_mod=3)
     assert n == 3 and net.feature_fields.batch_size == 0
     res = DD.gather_metrics(sums, n, device="cuda")
     assert res["episodes"] == 3.0 and 1.0 <= res["steps_taken"] <= 5.0
@@ -159,6 +161,7 @@ def test_policy_forward_generates_text_with_kv_cache():
     from dynam3d_amd.policy import Dynam3D_VLN, synth_policy_weights
     from dynam3d_amd.synthetic import INSTRUCTION_64, SyntheticEpisodes
     cfg = dataclasses.replace(SMALL, clip_dtype=torch.float16, llava_dtype=torch.bfloat16)
+    from dynam3d_amd import dense_ops as D
     net = Dynam3D_VLN(cfg, synth_policy_weights(cfg, 0), device="cuda", batch_size=2, max_steps=4)
     net.feature_fields.initialize_camera_setting(90.0, 90.0)
     ep = SyntheticEpisodes(2, seed=3, image_hw=224, depth_hw=224)
@@ -166,7 +169,8 @@ def test_policy_forward_generates_text_with_kv_cache():
     for _ in range(2):
         fr = ep.next()
         obs = dict(rgb=torch.from_numpy(fr.rgb), depth=torch.from_numpy(fr.depth))
-        texts = net(obs, [INSTRUCTION_64] * 2, [p.tolist() for p in fr.positions], list(fr.headings), patch_segm=fr.patch_segm, max_new_tokens=5)
+        with D.allow_fallback():                                        # toy widths (SMALL): below the HIP kernels' tiles
+            texts = net(obs, [INSTRUCTION_64] * 2, [p.tolist() for p in fr.positions], list(fr.headings), patch_segm=fr.patch_segm, max_new_tokens=5)
         assert len(texts) == 2 and all(isinstance(t, str) for t in texts)
         acts = net.convert_text_to_action(texts)
         assert len(acts) == 2
@@ -213,3 +217,29 @@ def test_bench_gpus_n_without_launcher_spawns_n_ranks_or_refuses():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+
+
+def test_a_cuda_call_without_a_hip_kernel_raises_by_default():
+    """Strict is the DEFAULT of dense_ops: a CUDA tensor whose shape / dtype has no hand-written kernel raises instead of running the
+    PyTorch expression (hipBLASLt / SDPA); `allow_fallback()` is the explicit opt-out and is counted; CPU tensors always take the
+    expression."""
+    import pytest
+    from dynam3d_amd import dense_ops as D
+    assert D.STRICT
+    D.enable_hip_kernels(["all"])
+    x, w = torch.randn(40, 100, device="cuda", dtype=torch.bfloat16), torch.randn(72, 100, device="cuda", dtype=torch.bfloat16)   # N % 128, K % 64 both fail
+    with pytest.raises(D.DenseFallbackError):
+        D.linear(x, w, None)
+    with pytest.raises(D.DenseFallbackError):
+        D.linear(x.float(), w.float(), None)                                      # float32 operands: no 16-bit GEMM
+    with pytest.raises(D.DenseFallbackError):
+        D.rms_norm(torch.randn(4, 100, device="cuda", dtype=torch.bfloat16), torch.ones(100, device="cuda"), 1e-5)
+    with pytest.raises(D.DenseFallbackError):
+        D.attention_qkv(torch.randn(1, 8, 6, 32, device="cuda", dtype=torch.bfloat16), 2, True)            # head_dim 32
+    D.reset_counts()
+    with D.allow_fallback():
+        y = D.linear(x, w, None)
+    assert D.STRICT and D.counts()["fallback"] == {"linear": 1}
+    assert torch.allclose(y.float(), (x.float() @ w.float().T), atol=0.5, rtol=5e-2)
+    assert D.linear(x.cpu().float(), w.cpu().float(), None).shape == (40, 72)      # CPU tensors: the expression, never counted
+    assert D.counts()["fallback"] == {"linear": 1}

@@ -9,7 +9,7 @@ import torch
 
 from oracle import geometry as G
 from oracle.ff_oracle import FeatureFieldsOracle
-from tests.golden_io import TRAJ_CASES, GOLDEN_DIR, load, traj_inputs, unpack_ragged
+from tests.golden_io import TRAJ_CASES, GOLDEN_DIR, int_hash, load, pack_ragged, traj_inputs, unpack_ragged
 from dynam3d_amd.weights import ff_param_spec, synth_state_dict
 
 
@@ -49,17 +49,25 @@ def check_env_against_golden(g, t, b, owner, members, zmembers, zkey, ipos, ifts
     """Shared by the oracle test here and the GPU parity test: exact bookkeeping, toleranced floats."""
     p = f"t{t}_b{b}_"
     ks = np.array(sorted(owner.keys()), np.int64)
-    assert np.array_equal(ks, g[p + "owner_ids"])
-    assert np.array_equal(np.array([owner[k] for k in ks.tolist()], np.int64), g[p + "owner_inst"])
-    assert np.array_equal(np.array(list(members.keys()), np.int64), g[p + "inst_order"])
-    for a, e in zip(unpack_ragged(g[p + "inst_members"], g[p + "inst_members_off"]), members.values()):
-        assert np.array_equal(a, np.asarray(e, np.int64))
-    assert np.array_equal(np.array(list(zmembers.keys()), np.int64), g[p + "zone_order"])
-    for a, e in zip(unpack_ragged(g[p + "zone_members"], g[p + "zone_members_off"]), zmembers.values()):
-        assert np.array_equal(a, np.asarray(e, np.int64))
+    owner_inst = np.array([owner[k] for k in ks.tolist()], np.int64)
+    assert np.array_equal(np.array(list(members.keys()), np.int64), g[p + "inst_order"]), (t, b)
+    assert np.array_equal(np.array(list(zmembers.keys()), np.int64), g[p + "zone_order"]), (t, b)
+    if p + "book_hash" in g.files:      # light step of a long trajectory: digests of the same tables (tests/golden/gen_golden.py)
+        im, imo = pack_ragged([np.asarray(m, np.int64) for m in members.values()])
+        zmm, zmo = pack_ragged([np.asarray(m, np.int64) for m in zmembers.values()])
+        assert int(g[p + "n_rows"]) == rows_pos.shape[0], (t, b)
+        assert int_hash(ks, owner_inst, im, imo, zmm, zmo) == int(g[p + "book_hash"]), (t, b)
+        assert int_hash(np.ascontiguousarray(rows_pos, np.float32).view(np.uint32)) == int(g[p + "rows_hash"]), (t, b)
+    else:
+        assert np.array_equal(ks, g[p + "owner_ids"])
+        assert np.array_equal(owner_inst, g[p + "owner_inst"])
+        for a, e in zip(unpack_ragged(g[p + "inst_members"], g[p + "inst_members_off"]), members.values()):
+            assert np.array_equal(a, np.asarray(e, np.int64))
+        for a, e in zip(unpack_ragged(g[p + "zone_members"], g[p + "zone_members_off"]), zmembers.values()):
+            assert np.array_equal(a, np.asarray(e, np.int64))
+        assert np.array_equal(bits(rows_pos), bits(g[p + "rows_pos"]))
     assert np.array_equal(np.array(list(zkey.keys()), np.float32).reshape(-1, 3), g[p + "zone_keys"])
     assert np.array_equal(np.array(list(zkey.values()), np.int64), g[p + "zone_key_ids"])
-    assert np.array_equal(bits(rows_pos), bits(g[p + "rows_pos"]))
     # merged centroids average tomb-stoned rows (-1e4) in float32 in the reference (F11): tolerance
     # is relative to the magnitude of the summands.
     tol = lambda ref: 2e-6 * np.maximum(1.0, np.abs(ref)) + 2e-7 * 1e4

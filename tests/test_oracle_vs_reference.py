@@ -10,7 +10,9 @@ from dynam3d_amd.weights import ff_param_spec, synth_state_dict
 
 @pytest.mark.reference
 @pytest.mark.parametrize("case", [dict(B=1, steps=4, seed=11, grid_seed=12, stationary=False, wall=None, depth_hw=96),
-                                  dict(B=1, steps=4, seed=13, grid_seed=14, stationary=True, wall=1.5, depth_hw=48)])
+                                  dict(B=1, steps=4, seed=13, grid_seed=14, stationary=True, wall=1.5, depth_hw=48),
+                                  # 30 live steps, fresh seed, wall steps: deletions, recycled ids and stale zone snapshots at bench-like depth
+                                  dict(B=2, steps=30, seed=31, grid_seed=32, stationary=False, wall=2.0, wall_steps=(7, 8, 16, 24), depth_hw=64)])
 def test_oracle_matches_reference_live(case):
     from oracle import ref_harness as rh
     from oracle.ff_oracle import FeatureFieldsOracle

@@ -22,8 +22,23 @@ MID = PolicyConfig(vit=VitConfig(image=336, patch=14, width=256, layers=2, heads
                    clip_dtype=torch.float16, llava_dtype=torch.bfloat16)
 
 
+def toy_dense(cfg, device):
+    """Context for a run of `cfg` on `device`: toy tower configurations (float32 towers, widths below the HIP kernels' 128 x 64 tiles)
+    on a GPU have no HIP kernel for their dense primitives -- they opt out of dense_ops' strict default EXPLICITLY; everything
+    else (MID, the full configuration, the CPU) runs under the default."""
+    import contextlib
+    from dynam3d_amd import dense_ops as D
+    toy = cfg.clip_dtype == torch.float32 or cfg.llava_dtype == torch.float32 or cfg.vit.width % 128 or cfg.llm.hidden % 128
+    return D.allow_fallback() if (str(device) != "cpu" and toy) else contextlib.nullcontext()
+
+
 def run_policy_vs_oracle(ops, device, cfg, steps=3, B=2, tol=2e-4, check_embeds=True, lowp_oracle=False):
     """lowp_oracle: the oracle evaluates the towers in cfg's dtypes with the reference's rounding points (towers_ref `lowp`)."""
+    with toy_dense(cfg, device):
+        return _run_policy_vs_oracle(ops, device, cfg, steps, B, tol, check_embeds, lowp_oracle)
+
+
+def _run_policy_vs_oracle(ops, device, cfg, steps, B, tol, check_embeds, lowp_oracle):
     sd = synth_policy_weights(cfg, seed=0)
     net = Dynam3D_VLN(cfg, sd, device=device, batch_size=B, ops=ops, max_steps=steps + 1)
     net.feature_fields.initialize_camera_setting(90.0, 90.0)

@@ -92,7 +92,7 @@ def test_closed_loop_rollout_full_model_8x50():
         torch.cuda.synchronize()
         dt = time.time() - t0
     finally:
-        D.strict(False)
+        D.strict(True)                                              # (the default)
     kinds = {("stop" if a is None else "move") for t in trace for a in t["actions"]}
     alive = [len(t["texts"]) for t in trace] + [0]
     lens = sorted(k + 1 for k in range(len(trace)) for _ in range(alive[k] - alive[k + 1]))          # episode k ended after its step k

@@ -277,4 +277,4 @@ def test_checkpoint_round_trip_on_the_hip_kernels():
                            num_of_views=1, is_train=False, patch_segm=frames[0][3])
         assert len(texts) == B and len(policy.net.convert_text_to_action(texts)) == B
     finally:
-        D.strict(False)
+        D.strict(True)                                              # (the default)
