@@ -32,9 +32,10 @@ def _unit(x, eps=0.0):
 
 def alignment_loss(pred_inst, tgt_inst, pred_inst_sub, tgt_inst_sub, pred_zone: Optional[torch.Tensor] = None, tgt_zone=None,
                    pred_zone_sub=None, tgt_zone_sub=None) -> torch.Tensor:
-    p, t = _unit(pred_inst), _unit(tgt_inst)
+    # float16 targets (means of the float16 CLIP features) are normalised in float16 like the reference's (PRE-FF:1307, 1314), then promoted
+    p, t = _unit(pred_inst), _unit(tgt_inst).float()
     loss = contrastive_loss(p, t) / 5.0 + (1.0 - (p * t).sum(-1)).mean()
-    ps, ts = _unit(pred_inst_sub, 1e-7), _unit(tgt_inst_sub, 1e-7)
+    ps, ts = _unit(pred_inst_sub, 1e-7), _unit(tgt_inst_sub, 1e-7).float()
     loss = loss + (1.0 - (ps * ts).sum(-1)).mean()
     if pred_zone is not None:
         pz, tz = _unit(pred_zone), _unit(tgt_zone)

@@ -228,12 +228,14 @@ class FFTrainer:
         tok = tok_fts.float()
         pred = m.encode_patch_sets(tok, geom7, lens)                                                   # PRE-FF:960-964
         grp_of_tok = torch.from_numpy(np.repeat(np.arange(len(valid_g)), lens)).to(dev)
-        seg_mean = torch.zeros((len(valid_g), tok.shape[1]), device=dev).index_add_(0, grp_of_tok, tok) / torch.from_numpy(lens).to(dev).float()[:, None]
-        frame_mean = tok.view(B, P, -1).mean(1)                                                        # patch_fts.mean(0) of every environment
+        # The targets are means of float16 CLIP features and the reference evaluates them IN float16 (`patch_fts[...].mean(0)` on a half
+        # tensor, half - half, PRE-FF:969-972; the losses normalise them in half too, losses.alignment_loss): same rounding points here.
+        seg_mean = (torch.zeros((len(valid_g), tok.shape[1]), device=dev).index_add_(0, grp_of_tok, tok) / torch.from_numpy(lens).to(dev).float()[:, None]).half()
+        frame_mean = tok.view(B, P, -1).mean(1).half()                                                 # patch_fts.mean(0) of every environment
         env_of_grp = torch.from_numpy(valid_g // n_max).to(dev)
         fm = frame_mean.index_select(0, env_of_grp)
         self.pred_i.append(pred); self.tgt_i.append(seg_mean)                                          # PRE-FF:969-974
-        self.pred_is.append(pred - fm); self.tgt_is.append(seg_mean - fm)
+        self.pred_is.append(pred - fm.float()); self.tgt_is.append(seg_mean - fm)
         cen = centroid.index_select(0, torch.from_numpy(valid_g).to(dev))
         if image_ft_ix is not None:                                                                    # PRE-FF:992-1008: the frame's instances as ONE zone
             n_inst = np.bincount(valid_g // n_max, minlength=B)

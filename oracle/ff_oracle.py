@@ -59,6 +59,7 @@ class _Env:
         self.zpos = np.zeros((0, 3), F32)
         self.zfts = np.zeros((0, 768), F32)
         self.tree = None  # snapshot of ipos (torch_kdtree copies on build)
+        self.row_gt = np.zeros((0,), np.int64)   # training: GT instance id of every instance row (PRE-FF `global_gt_instance_ids`)
 
 
 class FeatureFieldsOracle:
@@ -145,6 +146,8 @@ class FeatureFieldsOracle:
                         key = tuple(G.zone_cell_centre(e.ipos[inst:inst + 1], self.cell)[0].tolist())
                         e.ipos[inst] = G.TOMBSTONE
                         e.ifts[inst] = 0
+                        if inst < e.row_gt.shape[0]:
+                            e.row_gt[inst] = -10000                      # PRE-FF:728
                         if key in e.zkey:
                             zid = e.zkey[key]
                             e.zmembers[zid] = e.zmembers[zid][e.zmembers[zid] != inst]
@@ -159,8 +162,15 @@ class FeatureFieldsOracle:
     @torch.no_grad()
     def update_feature_fields(self, batch_depth24, batch_grid_ft, patch_segm, batch_position=None, batch_heading=None, num_of_views=1,
                               view_ids=None, batch_camera_intrinsic=None, batch_rot=None, batch_trans=None, depth_scale=1000.0,
-                              depth_trunc=1000.0, view_hw=(12, 12)):
-        """batch_depth24 (B,V,P) metres; batch_grid_ft (B,V,P,768); patch_segm (B,V,H,W) or (B*V,1,H,W)
+                              depth_trunc=1000.0, view_hw=(12, 12), train=None):
+        """train = dict(gt_xyz=[(Ng,3) f32 per env], gt_label=[(Ng,) int per env], image_ft=(B,V,768) f32 or None): the Pretrain class's
+        `is_training=True` branch (PRE-FF:843-1345) FROM RAW INPUTS -- every segment is labelled with the majority GT id of its patches'
+        nearest GT points (PRE-FF:976-983), the memory merges by ground truth (PRE-FF:1029-1035), and the inputs of every loss term are
+        recorded in `self.train_views` (one record per (environment, view), the format of oracle/train_ref.training_loss_and_grads)
+        together with the integer by-products the reference returns (`self.train_ints`).  The module arithmetic is the inference one
+        (dropout off: the goldens' p = 0 convention, oracle/ref_harness.RefTrainingRun).
+
+        batch_depth24 (B,V,P) metres; batch_grid_ft (B,V,P,768); patch_segm (B,V,H,W) or (B*V,1,H,W)
         dense labels; positions habitat xyz; headings rad.  `view_ids` (Pretrain signature, PRE-FF:843,920): view ix looks
         along heading - view_ids[ix]*pi/6 instead of heading - ix*pi/6 (VLN-FF:550); with is_training=False and no GT point
         cloud the Pretrain update is otherwise the same state machine (diffed, SURVEY.md 8 note under a23)."""
@@ -174,6 +184,8 @@ class FeatureFieldsOracle:
         vid = list(range(num_of_views)) if view_ids is None else [int(v) for v in view_ids]
         segm_all = np.asarray(patch_segm).reshape(self.batch_size, num_of_views, P)
         self.last_debug = []
+        self.train_views = []
+        self.train_ints = dict(gt_nn=[[] for _ in self.env], gt3d=[[] for _ in self.env], gt_in_zone=[[] for _ in self.env])
         for b, e in enumerate(self.env):
             for ix in range(num_of_views):
                 dbg = {}
@@ -200,6 +212,25 @@ class FeatureFieldsOracle:
                     new_pos[i] = G.mean_rows_f64(pos[sel])
                     new_fts[i] = self._encode_patches(pos[sel], direction[sel], scale[sel], fts16[sel], new_pos[i])
                 dbg["new_pos"], dbg["new_fts"] = new_pos.copy(), new_fts.copy()
+                gt_seg = rec = None
+                if train is not None:
+                    gxyz, glab = np.asarray(train["gt_xyz"][b], F32), np.asarray(train["gt_label"][b], np.int64)
+                    gt_seg = np.zeros((n,), np.int64)
+                    toks, geoms, lens = [], [], []
+                    for i, s in enumerate(labels):
+                        sel = segm == s
+                        _, nn = G.knn_bruteforce(gxyz, pos[sel], 1)                    # k = 1 nearest GT point of every patch (PRE-FF:978)
+                        self.train_ints["gt_nn"][b].append(nn[:, 0].astype(np.int64))
+                        vals, cnt = np.unique(glab[nn[:, 0]], return_counts=True)
+                        gt_seg[i] = vals[cnt.argmax()]                                 # unique_vals[counts.argmax()] (PRE-FF:982-983)
+                        toks.append(fts16[sel]); lens.append(int(sel.sum()))
+                        geoms.append(G.segment_geometry(pos[sel], direction[sel], scale[sel], new_pos[i]))
+                    img = train.get("image_ft")
+                    rec = dict(tok_fts=np.concatenate(toks, 0), geom7=np.concatenate(geoms, 0).astype(F32), lens=np.asarray(lens, np.int64),
+                               cen=new_pos.copy(), env_of_group=np.zeros((n,), np.int64), B=1, P=P, frame_fts=fts16.copy(),
+                               img_ix=None if img is None else np.asarray(img[b][ix:ix + 1], F32),
+                               img_mean=None if img is None else np.asarray(img[b], F32).mean(0, keepdims=True), gt=gt_seg.copy(), pairs=None)
+                    self.train_views.append(rec)
 
                 if e.tree is not None:
                     d2, idx = G.knn_bruteforce(e.tree, new_pos, proposal_num)
@@ -213,6 +244,11 @@ class FeatureFieldsOracle:
                         x = np.concatenate([e.ifts[idx], np.repeat(new_fts[:, None, :], proposal_num, 1), delta], -1)
                         logits = NN.mlp_ln_gelu(torch.from_numpy(x), self.sd, "instance_merge_discriminator").numpy()
                         target = np.argmax(logits, -1)                  # == argmax(softmax)
+                        if train is not None:                           # merge by GROUND TRUTH (PRE-FF:1031-1035)
+                            target = (e.row_gt[idx] == gt_seg[:, None]).astype(np.int64)
+                            rec["pairs"] = dict(f3=e.ifts[idx].reshape(-1, 768).copy(), p3=e.ipos[idx].reshape(-1, 3).copy(),
+                                                g=np.repeat(np.arange(n), proposal_num), target=target.reshape(-1).copy(),
+                                                pe=np.zeros((n * proposal_num,), np.int64))
                     else:
                         logits = np.zeros((n, 0, 2), F32)
                         target = np.zeros((n, 0), np.int64)
@@ -231,9 +267,15 @@ class FeatureFieldsOracle:
                                 e.owner[p_] = inst
                             if inst < e.ipos.shape[0]:
                                 e.ipos[inst], e.ifts[inst] = new_pos[s], new_fts[s]
+                                if train is not None:
+                                    e.row_gt[inst] = gt_seg[s]
                             else:
                                 e.ipos = np.concatenate([e.ipos, new_pos[s:s + 1]], 0)
                                 e.ifts = np.concatenate([e.ifts, new_fts[s:s + 1]], 0)
+                                if train is not None:
+                                    e.row_gt = np.concatenate([e.row_gt, gt_seg[s:s + 1]], 0)
+                            if train is not None:
+                                self.train_ints["gt3d"][b].append(int(gt_seg[s]))
                         else:
                             j = int(np.nonzero(target[s])[0][0])       # first positive proposal only
                             inst = int(idx[s, j])
@@ -244,6 +286,8 @@ class FeatureFieldsOracle:
                             cen = G.mean_rows_f64(e.pos[rows])
                             e.ipos[inst] = cen
                             e.ifts[inst] = self._encode_patches(e.pos[rows], e.dir[rows], e.scale[rows], e.fts[rows], cen)
+                            if train is not None:
+                                self.train_ints["gt3d"][b].append(int(e.row_gt[inst]))
                     # zones (VLN-FF:694-756)
                     gz = G.zone_cell_centre(e.ipos, self.cell)
                     uz = G.zone_cell_centre(new_pos, self.cell)
@@ -257,6 +301,7 @@ class FeatureFieldsOracle:
                             zid = int(zone_ids[nz]); nz += 1
                             e.zkey[key] = zid
                             e.zmembers[zid] = np.nonzero(mask)[0]
+                            self.train_ints["gt_in_zone"][b].append(e.zmembers[zid].astype(np.int64))
                             pset = e.ipos[mask]
                             cen = self._mean(pset)
                             e.zpos = np.concatenate([e.zpos, cen[None]], 0)            # quirk Z1: append
@@ -265,6 +310,7 @@ class FeatureFieldsOracle:
                         else:
                             zid = e.zkey[key]
                             e.zmembers[zid] = np.nonzero(mask)[0]
+                            self.train_ints["gt_in_zone"][b].append(e.zmembers[zid].astype(np.int64))
                             pset = gz[mask]                                            # quirk Z2: cell centres
                             cen = self._mean(pset)
                             e.zpos[zid] = cen
@@ -272,6 +318,9 @@ class FeatureFieldsOracle:
                 else:
                     # first frame of the episode (VLN-FF:759-812)
                     e.ipos, e.ifts = new_pos.copy(), new_fts.copy()
+                    if train is not None:
+                        e.row_gt = gt_seg.copy()
+                        self.train_ints["gt3d"][b].extend(int(g) for g in gt_seg)
                     inst_ids = lowest_unused(e.members.keys(), n)
                     new_patch_ids = lowest_unused(e.owner.keys(), P)
                     dbg["new_patch_ids"] = new_patch_ids.copy()
@@ -290,6 +339,7 @@ class FeatureFieldsOracle:
                         zid = int(zone_ids[zi])
                         e.zkey[key] = zid
                         e.zmembers[zid] = np.nonzero(mask)[0]
+                        self.train_ints["gt_in_zone"][b].append(e.zmembers[zid].astype(np.int64))
                         pset = new_pos[mask]
                         cen = self._mean(pset)
                         e.zpos = np.concatenate([e.zpos, cen[None]], 0)

@@ -256,3 +256,103 @@ class RefFeatureFields:
         F.update_feature_fields(depth24, grid_fts, batch_image=img, batch_position=positions,
                                 batch_heading=headings, num_of_views=num_of_views)
         return F.get_environment_features(positions, headings)
+
+
+# --------------------------------------------------------------------------------------------
+# PRE-FF:843-1345 with is_training=True, executed on the CPU
+# --------------------------------------------------------------------------------------------
+class _RecordingTree:
+    """Wraps a GT point-cloud tree: every k = 1 query's nearest-point indices are logged (PRE-FF:978: one call per 2D segment)."""
+
+    def __init__(self, tree, log):
+        self.tree, self.log = tree, log
+
+    def query(self, q, nr_nns_searches=1):
+        d, idx = self.tree.query(q, nr_nns_searches=nr_nns_searches)
+        self.log.append(idx[:, 0].numpy().astype(np.int64).copy())
+        return d, idx
+
+
+class _PromotingMatmul:
+    """The training branch multiplies float32 predictions with the float16 CLIP targets (`contrastive_loss`, PRE-FF:836); under the CUDA
+    autocast the reference trains in (PRE-TR:501) that runs, on the CPU `torch.matmul` rejects mixed dtypes.  This context promotes mixed
+    operands to their common dtype (float32) -- the ONE shim the CPU execution needs; everything else is the reference's own code."""
+
+    def __enter__(self):
+        self.orig = torch.matmul
+
+        def mm(a, b, *args, **kw):
+            if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.dtype != b.dtype:
+                dt = torch.promote_types(a.dtype, b.dtype)
+                a, b = a.to(dt), b.to(dt)
+            return self.orig(a, b, *args, **kw)
+
+        torch.matmul = mm
+        return self
+
+    def __exit__(self, *exc):
+        torch.matmul = self.orig
+        return False
+
+
+class RefTrainingRun(RefFeatureFields):
+    """Drives the reference's Pretrain `Feature_Fields.update_feature_fields(is_training=True)` -- GT labelling (PRE-FF:976-986), GT merges
+    (PRE-FF:1029-1047), loss assembly (PRE-FF:1302-1345) -- on the CPU: habitat mode, view_ids (0, 3, 6, 9), a synthetic GT instance point
+    cloud per environment, CLIP image features per view.  The module is in eval() mode: dropout (0.1 inside the encoder layers while
+    the reference trains) is OFF, i.e. the goldens made with this class encode the p = 0 arithmetic."""
+
+    def __init__(self, batch_size, state_dict, gt_xyz, gt_label):
+        super().__init__(batch_size, state_dict, which="pre")
+        self.gt_log = [[] for _ in range(batch_size)]
+        # mode "scannet": the GT cloud is used as given ("habitat" subtracts the 1.25 m agent height from z, PRE-FF:296-297)
+        self.F.reset(batch_size, mode="scannet", batch_gt_pcd_xyz=[torch.from_numpy(np.asarray(x, np.float32)) for x in gt_xyz],
+                     batch_gt_pcd_label=[torch.from_numpy(np.asarray(l, np.int64)) for l in gt_label])
+        self.F.initialize_camera_setting(90.0, 90.0)
+        self._wrap_stores()
+        self.F.gt_pcd_tree = [_RecordingTree(t, self.gt_log[b]) for b, t in enumerate(self.F.gt_pcd_tree)]
+
+    def train_step(self, depth_full, depth24, grid_fts, patch_segm, positions, headings, view_ids, image_ft, backward=True):
+        """One delete + update(is_training=True).  image_ft (B, V, 768) float32 torch.  Returns a dict with the two losses, the returned
+        GT-id / feature lists, the cross-entropy calls' (score, target) pairs and -- with `backward` -- every parameter's gradient of
+        sim_loss + segm_loss."""
+        import torch.nn.functional as TF
+        F = self.F
+        B, V = F.batch_size, len(view_ids)
+        vid = _ViewIds(view_ids)
+        for l in self.gt_log:
+            l.clear()
+        with torch.no_grad():
+            F.delete_old_features_from_camera_frustum(depth_full, positions, headings, view_ids=vid)
+        self._wrap_stores()
+        self._segm = patch_segm
+        img = np.zeros((B, V, 8, 8, 3), np.uint8)
+        ce_calls = []
+        orig_ce = TF.cross_entropy
+
+        def ce(inp, tgt, *a, **k):
+            if inp.dim() == 2 and inp.shape[-1] == 2:
+                ce_calls.append((inp.detach().numpy().copy(), tgt.detach().numpy().copy()))
+            return orig_ce(inp, tgt, *a, **k)
+
+        F.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy = ce
+        try:
+            with _PromotingMatmul():
+                out = F.update_feature_fields(depth24, grid_fts, batch_image=img, batch_image_ft=image_ft, batch_position=positions,
+                                              batch_heading=headings, view_ids=vid, is_training=True)
+        finally:
+            torch.nn.functional.cross_entropy = orig_ce
+        sim, segm, gt3d, pred3d, gt_in_zone, pred_zone = out
+        res = dict(sim_loss=float(sim.detach()), segm_loss=float(segm.detach()) if isinstance(segm, torch.Tensor) else float(segm),
+                   has_segm=isinstance(segm, torch.Tensor), gt3d=[g.numpy().astype(np.int64).copy() for g in gt3d],
+                   pred3d=[p.detach().numpy().copy() for p in pred3d],
+                   gt_in_zone=[[z.numpy().astype(np.int64).copy() for z in zs] for zs in gt_in_zone],
+                   pred_zone=[[z.detach().numpy()[0].copy() for z in zs] for zs in pred_zone],
+                   ce_calls=ce_calls, gt_nn=[[a.copy() for a in l] for l in self.gt_log],
+                   row_gt=[np.asarray(g.numpy() if isinstance(g, torch.Tensor) else g, np.int64).copy() for g in F.global_gt_instance_ids])
+        if backward:
+            loss = sim + segm if isinstance(segm, torch.Tensor) else sim
+            loss.backward()
+            res["grads"] = {k: (p.grad.detach().numpy().copy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32))
+                            for k, p in F.named_parameters() if not k.startswith(("FastSAM", "nerf_", "patch_to_nerf_", "aggregate_patch_to_nerf_"))}
+        return res

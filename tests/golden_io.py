@@ -45,6 +45,31 @@ def int_hash(*arrays) -> np.int64:
     return np.frombuffer(h.digest()[:8], np.int64)[0]
 
 
+def make_gt(n_points, seed=0):
+    """A synthetic ground-truth instance point cloud (Pretrain `gt_pcd_xyz` / `gt_pcd_label`): uniform points, instance id = the 1.5 m
+    cell they fall into."""
+    rng = np.random.default_rng(seed)
+    xyz = np.stack([rng.uniform(-9, 9, n_points), rng.uniform(-9, 9, n_points), rng.uniform(-3, 4, n_points)], 1).astype(np.float32)
+    lab = (np.floor(xyz[:, 0] / 1.5).astype(np.int64) + 8) * 64 + (np.floor(xyz[:, 1] / 1.5).astype(np.int64) + 8)
+    return xyz, lab
+
+
+# Golden g21 (tests/golden/gen_golden_train.py): the reference's `update_feature_fields(is_training=True)` on the Pretrain panorama case
+TRAIN_CASE = dict(traj="prepano", n_gt=20000, gt_seed=3, img_seed=77, steps=3)
+
+
+def train_inputs(tc=TRAIN_CASE):
+    """-> (case, gts [(xyz, label) per env], generator of (step inputs, image_ft (B, V, 768) float32))."""
+    case = dict(TRAJ_CASES[tc["traj"]], steps=tc["steps"])
+    gts = [make_gt(tc["n_gt"], seed=tc["gt_seed"] + b) for b in range(case["B"])]
+    rng = np.random.default_rng(tc["img_seed"])
+
+    def gen():
+        for inp in traj_inputs(case):
+            yield inp, rng.standard_normal((case["B"], len(case["view_ids"]), 768)).astype(np.float32)
+    return case, gts, gen()
+
+
 def traj_inputs(case):
     """Yields one dict per step for the environments still alive (see `pop`): depth_full (B,V,H,W), depth24 (B,V,576),
     grid (B,V,576,768), patch_segm (B*V,1,24,24) environment-major, positions, headings."""
