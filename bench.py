@@ -68,50 +68,109 @@ def _physical_cores():
     return os.cpu_count() or 1
 
 
+THREAD_SWEEP = {}       # threads -> seconds of the probe (printed in the cpu_baseline block)
+
+
 def _best_threads(limit):
-    """torch's fp32 GEMM does not always scale to every core of a large host: take the fastest of a few thread counts up to
-    `limit` (1 s probe)."""
+    """torch's fp32 GEMM does not always scale to every core of a large host: take the fastest of a few thread counts up to `limit` on
+    a PREFILL-SHAPED product -- one prompt's rows through one Phi-3 down projection, (821 x 8192) @ (8192 x 3072): the Phi-3 prefill is
+    75 % of the CPU leg, and a square 2048^3 probe (rounds 2-4) picked thread counts that were 2x apart from round to round on the same
+    oracle.  Best of 3 repetitions per count; the sweep is reported."""
     best, best_t = min(8, limit), float("inf")
-    a = torch.randn(2048, 2048)
-    cand = sorted({n for n in (8, 16, 32, 64, 96, 128, 192, limit) if n <= limit})
+    a, w = torch.randn(821, 8192), torch.randn(3072, 8192)
+    cand = sorted({n for n in (8, 16, 32, 48, 64, 96, 128, 192, limit) if n <= limit})
     for n in cand:
         torch.set_num_threads(n)
-        a @ a
-        t0 = time.time()
+        torch.nn.functional.linear(a, w)
+        t = float("inf")
         for _ in range(3):
-            a @ a
-        t = time.time() - t0
+            t0 = time.time()
+            torch.nn.functional.linear(a, w)
+            t = min(t, time.time() - t0)
+        THREAD_SWEEP[n] = round(t, 4)
         if t < best_t:
             best, best_t = n, t
     return best
 
 
-def parity_block(got, ref, lengths_equal):
+def _rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / max(np.linalg.norm(np.asarray(b, np.float64)), 1e-30))
+
+
+def prefix_rows_parity(gpu_prompt, orc_embeds, orc_lengths, counts, P=576):
+    """north_star's other quantity, "bf16 token features": the prefix rows handed to Phi-3 (VLN-POL:456: 2 text rows, P patch tokens, Ni
+    instance tokens, Nz zone tokens, text) of the GPU leg against the float32 oracle's at the same memory state, full size, per kind.
+    `floor` = the oracle's own rows rounded to bf16 against themselves: what ONE bf16 store costs (the rows ARE stored in bf16)."""
+    x, lengths = gpu_prompt
+    x = x.float().cpu().numpy()
+    off, acc = 0, {k: [0.0, 0.0, 0.0] for k in ("patch", "instance", "zone", "prefix")}
+    per_env = []
+    for b, n in enumerate(lengths):
+        g, o = x[off:off + n], orc_embeds[b, :orc_lengths[b]].numpy()
+        off += n
+        ni, nz = counts["Ni"][b], counts["Nz"][b]
+        cuts = dict(patch=(2, 2 + P), instance=(2 + P, 2 + P + ni), zone=(2 + P + ni, 2 + P + ni + nz), prefix=(2, 2 + P + ni + nz))
+        for k, (lo, hi) in cuts.items():
+            d, r = g[lo:hi].astype(np.float64) - o[lo:hi], o[lo:hi].astype(np.float64)
+            fl = torch.from_numpy(o[lo:hi]).to(torch.bfloat16).float().numpy().astype(np.float64) - r
+            acc[k][0] += float((d * d).sum()); acc[k][1] += float((r * r).sum()); acc[k][2] += float((fl * fl).sum())
+        lo, hi = cuts["prefix"]
+        per_env.append(round(_rel(g[lo:hi], o[lo:hi]), 6))
+    out = {k: round((v[0] / max(v[1], 1e-30)) ** 0.5, 6) for k, v in acc.items()}
+    return dict(what="rel L2 of the prefix token rows fed to Phi-3 (bf16) vs the float32 oracle's, first timed step, all %d environments" % len(lengths),
+                rel_l2=out, rel_l2_per_env_max=max(per_env), bf16_store_floor={k: round((v[2] / max(v[1], 1e-30)) ** 0.5, 6) for k, v in acc.items()},
+                north_star_1e3_met=bool(out["prefix"] < 1e-3),
+                note="patch tokens come out of the 23-layer bf16 llava tower (a 16-bit evaluation: same noise argument as the logits, DESIGN.md 5.1); "
+                     "instance / zone tokens are float32 up to their bf16 store")
+
+
+def parity_block(got, ref, lengths_equal, lowp=None):
     """The GPU leg's logits of the first timed step against the float32 CPU oracle's at the SAME memory state (B x vocab each).
-    Criterion = the 16-bit noise band: north_star's 1e-3 is below what two evaluations of this network in the reference's OWN dtypes
-    (fp16 CLIP, bf16 llava / Phi-3) can agree to -- golden g19 (full configuration, generated by the oracle in both arithmetics) holds the
-    distance between the reference-dtype evaluation and float32; the GPU leg must sit inside 1.25 x that band."""
-    rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
-    band, src = None, "tests/golden/g19_full_step.npz missing"
-    g19 = os.path.join(ROOT, "tests", "golden", "g19_full_step.npz")
-    if os.path.isfile(g19):
-        g = np.load(g19)
-        bands = [float(np.linalg.norm(g[f"logits_lowp_{t}"] - g[f"logits_f32_{t}"]) / np.linalg.norm(g[f"logits_f32_{t}"])) for t in range(int(g["steps"]))]
-        band, src = max(bands), "g19: reference-dtype (lowp) oracle vs float32 oracle, full configuration, B = 2, steps 0-1"
+    north_star's 1e-3 is below what two evaluations of this network in the reference's OWN dtypes (fp16 CLIP, bf16 llava / Phi-3) can
+    agree to; the criterion is therefore the 16-bit noise band -- the distance between the reference-dtype (`lowp`) oracle
+    and the float32 oracle:
+      * with `lowp` (bench.py --parity-lowp: the lowp oracle evaluated ON THIS RUN'S OWN STATE, same B, same memory step, same prompts) the
+        criterion is HARD: rel(GPU, float32) <= band and rel(GPU, lowp) <= band, no factor;
+      * without it the band of golden g19 (B = 2, steps 0-1: another operating point) is quoted for orientation only (`within_band` = null)."""
+    rel = _rel(got, ref)
+    per_row = [_rel(got[b], ref[b]) for b in range(got.shape[0])]
+    band = src = rel_lowp = hard = hard16 = hard32 = None
+    if lowp is not None:
+        band, rel_lowp = _rel(lowp, ref), _rel(got, lowp)
+        src = "the lowp (reference-dtype) oracle evaluated on THIS run's state: B = %d, same memory step, same prompts" % got.shape[0]
+        # Two hard comparisons, no factor.  vs lowp: the HIP evaluation differs from the reference-dtype oracle by no more than that oracle
+        # differs from exact arithmetic.  vs float32: the HIP evaluation's own distance from float32 is ONE MORE SAMPLE of the same 16-bit
+        # noise as the band (two evaluations with independent rounding noise of equal size sit at exactly the band: a coin flip) -- reported
+        # as measured.
+        hard16, hard32 = bool(rel_lowp <= band), bool(rel <= band)
+        hard = hard16 and hard32
+    else:
+        g19 = os.path.join(ROOT, "tests", "golden", "g19_full_step.npz")
+        if os.path.isfile(g19):
+            g = np.load(g19)
+            band = max(_rel(g[f"logits_lowp_{t}"], g[f"logits_f32_{t}"]) for t in range(int(g["steps"])))
+            src = "orientation only -- g19: lowp vs float32 oracle at B = 2, steps 0-1 (run bench.py --parity-lowp for the band at this operating point)"
     top1 = int((got.argmax(-1) == ref.argmax(-1)).sum())
     t5g, t5r = np.argsort(-got, -1)[:, :5], np.argsort(-ref, -1)[:, :5]
     top5 = float(np.mean([len(set(a.tolist()) & set(b.tolist())) / 5.0 for a, b in zip(t5g, t5r)]))
     srt = np.sort(ref, -1)
     margin = (srt[:, -1] - srt[:, -2]) / np.sqrt((ref.astype(np.float64) ** 2).mean(-1))      # the oracle's own top-2 margin in units of the logit rms
-    return dict(criterion="band (16-bit noise band of the reference's own dtypes; north_star's 1e-3 is below it, DESIGN.md 5.1)",
-                reference="float32 CPU oracle (oracle/step_oracle.py) at the GPU leg's memory state: full configuration, B = %d, first timed step" % got.shape[0],
-                logits_rel_l2=round(rel, 6), band=None if band is None else round(band, 6), band_source=src,
-                within_band=None if band is None else bool(rel < 1.25 * band), north_star_1e3_met=bool(rel < 1e-3),
-                top1_agree="%d/%d" % (top1, got.shape[0]), top5_overlap=round(top5, 3), oracle_top2_margin_in_rms=[round(float(m), 4) for m in margin],
-                same_prompt_lengths=bool(lengths_equal), weights="seeded random (no trained checkpoint offline)")
+    out = dict(criterion="hard: rel(GPU, f32) <= band AND rel(GPU, lowp) <= band, band = rel(lowp oracle, f32 oracle) at the SAME state" if lowp is not None
+               else "band quoted for orientation (no lowp leg in this run)",
+               reference="float32 CPU oracle (oracle/step_oracle.py) at the GPU leg's memory state: full configuration, B = %d, first timed step" % got.shape[0],
+               logits_rel_l2=round(rel, 6), logits_rel_l2_per_row_max=round(max(per_row), 6), logits_rel_l2_per_row=[round(r, 6) for r in per_row],
+               band=None if band is None else round(band, 6), band_source=src, logits_rel_l2_vs_lowp=None if rel_lowp is None else round(rel_lowp, 6),
+               within_band=hard, within_band_vs_lowp=hard16, within_band_vs_f32=hard32, north_star_1e3_met=bool(rel < 1e-3),
+               top1_agree="%d/%d" % (top1, got.shape[0]), top5_overlap=round(top5, 3), oracle_top2_margin_in_rms=[round(float(m), 4) for m in margin],
+               same_prompt_lengths=bool(lengths_equal), weights="seeded random (no trained checkpoint offline)")
+    if lowp is not None:
+        out["band_per_row"] = [round(_rel(lowp[b], ref[b]), 6) for b in range(got.shape[0])]
+        out["lowp_top1_agree_with_f32"] = "%d/%d" % (int((lowp.argmax(-1) == ref.argmax(-1)).sum()), got.shape[0])
+    return out
 
 
-def cpu_baseline(cfg, seed, B, warm_steps, gpu_lengths=None, gpu_grids=None, gpu_logits=None, sd=None, seconds_weights=None):
+def cpu_baseline(cfg, seed, B, warm_steps, gpu_lengths=None, gpu_grids=None, gpu_logits=None, sd=None, seconds_weights=None, gpu_prompt=None,
+                 gpu_counts=None, parity_lowp=False):
     """The whole-step float32 oracle ("port", oracle/step_oracle.py) MEASURED on the host cores at the benchmark's operating point:
     B environments, memory advanced `warm_steps` steps (3D-memory oracle on seeded unit-norm grid features -- the towers do not
     touch the memory), then ONE full step timed end to end: both ViT-L/14@336 towers on B frames, the 3D-token builder, the prefix
@@ -147,6 +206,15 @@ def cpu_baseline(cfg, seed, B, warm_steps, gpu_lengths=None, gpu_grids=None, gpu
     t_warm = time.time() - t_warm
     fr = ep.next()
     instr = [INSTRUCTION_64] * B
+    o16 = None
+    if parity_lowp and same_state:
+        # the reference-dtype oracle (fp16 CLIP, bf16 llava / Phi-3 with the reference's rounding points) on the SAME memory state: a copy of
+        # the 3D memory taken BEFORE the compared step (the memory is float32 and tower-independent up to here)
+        import copy
+        from oracle.ff_oracle import FeatureFieldsOracle
+        o16 = StepOracle(sd, cfg.vit, cfg.llm, B, tok, clip_dtype=cfg.clip_dtype, llava_dtype=cfg.llava_dtype)
+        o16.ff_threads = orc.ff_threads
+        o16.ff.env = copy.deepcopy(orc.ff.env)
     t0 = time.time()
     ref_logits = orc.forward_logits(fr.rgb, fr.depth, instr, [p.tolist() for p in fr.positions], list(fr.headings), fr.patch_segm)
     measured = time.time() - t0
@@ -162,10 +230,24 @@ def cpu_baseline(cfg, seed, B, warm_steps, gpu_lengths=None, gpu_grids=None, gpu
                           "the GPU leg's own CLIP grid features of every advance step (same memory state on both legs)" if same_state
                           else "seeded unit-norm grid features (so merge decisions -- and with them Ni/Nz and S -- differ from the GPU leg's)",
                           sum(orc.last_lengths), sum(gpu_lengths) if gpu_lengths else "n/a")),
-               memory_steps_advanced=warm_steps,
+               memory_steps_advanced=warm_steps, thread_sweep_seconds=dict(THREAD_SWEEP),
+               thread_probe="one prompt through one down projection: (821 x 8192) @ (8192 x 3072) float32, best of 3",
                seconds_measured=round(measured, 2), stages=st, seconds_weights=round(t_w, 1), seconds_memory_warmup=round(t_warm, 1))
     if same_state and gpu_logits is not None:
-        out["_parity"] = parity_block(np.asarray(gpu_logits, np.float32), np.asarray(ref_logits, np.float32), list(orc.last_lengths) == list(gpu_lengths or []))
+        lowp_logits = None
+        if o16 is not None:
+            t1 = time.time()
+            lowp_logits = np.asarray(o16.forward_logits(fr.rgb, fr.depth, instr, [p.tolist() for p in fr.positions], list(fr.headings), fr.patch_segm), np.float32)
+            out["seconds_lowp_oracle"] = round(time.time() - t1, 1)
+            if list(o16.last_lengths) != list(orc.last_lengths):
+                lowp_logits = None
+                out["lowp_oracle_note"] = "the lowp oracle's memory took different merge decisions at the compared step: no band"
+        out["_parity"] = parity_block(np.asarray(gpu_logits, np.float32), np.asarray(ref_logits, np.float32), list(orc.last_lengths) == list(gpu_lengths or []), lowp_logits)
+        if gpu_prompt is not None and list(orc.last_lengths) == list(gpu_prompt[1]) and gpu_counts is not None and orc.counts == gpu_counts:
+            try:
+                out["_parity"]["token_features"] = prefix_rows_parity(gpu_prompt, orc.last_embeds, orc.last_lengths, orc.counts)
+            except Exception as e:       # noqa: BLE001
+                out["_parity"]["token_features"] = {"error": repr(e)}
     # n = 8 threads (comparability with the survey container's probe), bounded: one environment's frame through both towers,
     # the B-environment memory step, Phi-3 on 2 of the layers; the full-step figure is the sum scaled to B frames / all layers.
     try:
@@ -215,6 +297,7 @@ def main():
     ap.add_argument("--hip-dense", default="all",
                     help="comma list of dense primitives on hand-written HIP kernels (linear,layer_norm,rms_norm,rope,swiglu,resize_normalize), 'all' or 'none'")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--parity-lowp", action="store_true", help="CPU leg: also run the reference-dtype (lowp) oracle on this run's own state (minutes of host time) -> the HARD parity criterion rel <= band")
     ap.add_argument("--no-decode", action="store_true", help="skip the generation figures (the `decode` object of the line) measured behind the timed region")
     a = ap.parse_args()
     launch_guard(a.gpus)
@@ -282,10 +365,13 @@ def main():
     D.reset_counts()
     lengths_seen = []
     t0 = time.perf_counter()
+    prompt_first = counts_first = None
     for i in range(a.warm_steps + a.warmup, total):
+        net.keep_prompt = do_cpu and rank == 0 and not lengths_seen     # (a reference to the first timed step's packed prompt rows: no copy)
         lo = run(i)
         if not lengths_seen:
             lo_first = lo                                       # logits of the first timed step (compared with the CPU oracle's below)
+            prompt_first, counts_first = net.last_prompt, dict(net.last_counts)
         lengths_seen.append(list(net.last_lengths))
     torch.cuda.synchronize()
     DD.barrier()
@@ -399,7 +485,7 @@ def main():
         if do_cpu:
             try:
                 cb = cpu_baseline(cfg, a.seed, B, a.warm_steps + a.warmup, lengths_seen[0], grids, lo_first.float().cpu().numpy(), sd=sd_cpu,
-                                  seconds_weights=t_weights)
+                                  seconds_weights=t_weights, gpu_prompt=prompt_first, gpu_counts=counts_first, parity_lowp=a.parity_lowp)
                 out["parity"] = cb.pop("_parity", None)
                 out["cpu_baseline"] = cb
             except Exception as e:  # never lose the GPU line because the host baseline failed

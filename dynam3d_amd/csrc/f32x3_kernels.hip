@@ -11,8 +11,14 @@
 // does not flush subnormal INPUTS -- tools/probe/denorm_probe.py), the dropped a_lo w_lo term is <= 2^-22 |a w|, products of fp16 values
 // are exact in the float32 accumulator: the result differs from a float32 GEMM by ~1e-6 relative, the size of a float32 summation-
 // order effect (tests/test_gpu_f32x3.py measures it against float64).  3 MFMAs at 16x the rate = 5.3x the float32 matrix peak.
-// Range: |x| < 65504 (CLIP features, LayerNorm outputs and GELU activations are O(1..100)); a finite input beyond that becomes inf and
-// the caller sees it -- the product wrapper (f32_ops.py) keeps the float32 kernel selectable (D3D_F32_SPLIT=0).
+// Range: none for finite operands, with the ROW EXPONENTS (round 5): every operand row is scaled by a power of two (exact) so that its
+// largest element lies in [1, 2) before the split -- `a_exp[m]` / `w_exp[n]` = floor(log2(max |row|)), computed by d3d_row_exponents
+// (once per weight, once per call for the activations) -- and the accumulator is scaled back by 2^(a_exp[m] + w_exp[n]) in the epilogue.
+// No finite row can overflow fp16 any more (|x| >= 65504 used to become inf), and a row of uniformly small values (1e-6: fp16 subnormals,
+// 4 significant bits) keeps its 22 bits.  Within a row, an element below 2^-14 of the row's maximum keeps only its hi half: an absolute
+// error <= 2^-25 x (row max) per element, invisible next to the row's leading terms in the same dot product.  Without exponent arrays
+// (null) the kernel is the unscaled round-3 one.  `status` (nullable): bit 0 is OR-ed in when an output element is not finite -- a device
+// word the caller reads when it pleases (the token builder: once per update, one step late, no synchronisation: f32_ops.py).
 //
 // Tile = (32 WT) x (32 WT) outputs per 256-thread workgroup, K step 32, every wave (16 WT)^2 = WT x WT tiles of v_mfma_f32_16x16x32_f16;
 // global float4 prefetch of the next K step in asm (see f32_kernels.hip for why), converted at the LDS write; LDS rows are
@@ -45,10 +51,15 @@ __device__ __forceinline__ void gload4(float4v& d, const float* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
 }
 
-__device__ __forceinline__ void split_store(_Float16* dst, const float4v v) {
+__device__ __forceinline__ float pow2f(int e) {          // 2^e, e in [-126, 127]
+    return __uint_as_float((uint32_t)(127 + e) << 23);
+}
+
+__device__ __forceinline__ void split_store(_Float16* dst, float4v v, const float sc) {
     half4 hi, lo;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+        v[r] *= sc;                                       // power of two: exact
         hi[r] = (_Float16)v[r];
         lo[r] = (_Float16)(v[r] - (float)hi[r]);
     }
@@ -59,7 +70,8 @@ __device__ __forceinline__ void split_store(_Float16* dst, const float4v v) {
 template <int EPI, int WT>
 __global__ void __launch_bounds__(256, 2)
 k_gemm_f32x3(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ C, const float* __restrict__ bias,
-             const float* __restrict__ residual, int M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int tiles_m, int tiles_n) {
+             const float* __restrict__ residual, int M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int tiles_m, int tiles_n,
+             const int32_t* __restrict__ a_exp, const int32_t* __restrict__ w_exp, int32_t* __restrict__ status) {
     constexpr int FBM = 32 * WT, FBN = 32 * WT, WAVE_T = 16 * WT;
     constexpr int NLD = FBM / 32;                                                 // float4 loads per thread and operand tile (rows lr + 32 j)
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_raw[];          // [buffer][A | W][FBM * XPITCH]: 72 KiB at WT = 4 (dynamic: > 64 KiB)
@@ -93,6 +105,13 @@ k_gemm_f32x3(const float* __restrict__ A, const float* __restrict__ W, float* __
         pa[j] = row_ptr(A, lda, row0 + lr + 32 * j, M) + lc;
         pw[j] = row_ptr(W, ldw, col0 + lr + 32 * j, N) + lc;
     }
+    float sa[NLD], sw[NLD];                                  // 2^-exponent of this thread's staged rows (1 without exponent arrays)
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int ra_ = min(row0 + lr + 32 * j, M - 1), rw_ = min(col0 + lr + 32 * j, N - 1);
+        sa[j] = a_exp ? pow2f(-a_exp[ra_]) : 1.0f;
+        sw[j] = w_exp ? pow2f(-w_exp[rw_]) : 1.0f;
+    }
     float4v ra[NLD], rw[NLD];
     auto issue = [&](int k) {
 #pragma unroll
@@ -109,8 +128,8 @@ k_gemm_f32x3(const float* __restrict__ A, const float* __restrict__ W, float* __
         }
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            split_store(smem[buf][0] + lds_off + 32 * j * XPITCH, ra[j]);
-            split_store(smem[buf][1] + lds_off + 32 * j * XPITCH, rw[j]);
+            split_store(smem[buf][0] + lds_off + 32 * j * XPITCH, ra[j], sa[j]);
+            split_store(smem[buf][1] + lds_off + 32 * j * XPITCH, rw[j], sw[j]);
         }
     };
     issue(0);
@@ -148,15 +167,21 @@ k_gemm_f32x3(const float* __restrict__ A, const float* __restrict__ W, float* __
         land(cur ^ 1);
         __syncthreads();
     }
+    bool bad = false;
 #pragma unroll
     for (int i = 0; i < WT; ++i) {
         const int m = row0 + wr * WAVE_T + i * 16 + fi;
         if (m >= M) continue;
+        const float back_a = a_exp ? pow2f(a_exp[m]) : 1.0f;
 #pragma unroll
         for (int j = 0; j < WT; ++j) {
             const int n = col0 + wc * WAVE_T + j * 16 + fg * 4;
             if (n >= N) continue;
             float4v v = acc[i][j];
+            if (a_exp || w_exp) {                             // undo the row scales: two exact multiplications (no intermediate overflow of 2^(ea + ew))
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (v[r] * back_a) * (w_exp ? pow2f(w_exp[n + r]) : 1.0f);
+            }
             if constexpr (EPI != F_NONE) {
                 const float4 b = *reinterpret_cast<const float4*>(bias + n);
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -169,8 +194,37 @@ k_gemm_f32x3(const float* __restrict__ A, const float* __restrict__ W, float* __
                 const float4 rr = *reinterpret_cast<const float4*>(residual + (int64_t)m * ldc + n);
                 v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
             }
+            bad |= !(fabsf(v[0]) <= 3.4028235e38f) | !(fabsf(v[1]) <= 3.4028235e38f) | !(fabsf(v[2]) <= 3.4028235e38f) | !(fabsf(v[3]) <= 3.4028235e38f);
             *reinterpret_cast<float4*>(C + (int64_t)m * ldc + n) = float4{v[0], v[1], v[2], v[3]};
         }
+    }
+    if (status && __any(bad) && lane == 0) atomicOr(status, 1);
+}
+
+// floor(log2(max |row|)) of every row (0 for an all-zero row; clamped to [-100, 100]); a non-finite element ORs bit 1 into `status` and is
+// left out of the maximum.  One wave per row.
+__global__ void __launch_bounds__(256)
+k_row_exponents(const float* __restrict__ X, int M, int K, int64_t ld, int32_t* __restrict__ out, int32_t* __restrict__ status) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* x = X + (int64_t)row * ld;
+    float mx = 0.f;
+    bool bad = false;
+    for (int k = lane * 4; k < K; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + k);
+        const float a[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (a[r] <= 3.4028235e38f) mx = fmaxf(mx, a[r]);
+            else bad = true;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (status && __any(bad) && lane == 0) atomicOr(status, 2);
+    if (lane == 0) {
+        int e = mx > 0.f ? (int)((__float_as_uint(mx) >> 23) & 0xff) - 127 : 0;      // (a subnormal maximum reads as -127: clamped below)
+        out[row] = max(-100, min(100, e));
     }
 }
 
@@ -178,8 +232,19 @@ k_gemm_f32x3(const float* __restrict__ A, const float* __restrict__ W, float* __
 
 extern "C" {
 
+int32_t d3d_row_exponents(const float* X, int32_t M, int32_t K, int64_t ld, int32_t* out, int32_t* status, void* stream) {
+    if (M <= 0) return D3D_OK;
+    if (K % 4 != 0 || K <= 0 || (ld & 3) || !X || !out) {
+        d3d_set_error_("d3d_row_exponents: need K % 4 == 0, ld % 4 == 0 and non-null buffers");
+        return D3D_EINVAL;
+    }
+    hipLaunchKernelGGL(k_row_exponents, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, M, K, ld, out, status);
+    D3D_LAUNCH_CHECK();
+}
+
 int32_t d3d_gemm_nt_f32x3(const float* A, const float* W, float* C, const float* bias, const float* residual, int32_t M, int32_t N, int32_t K,
-                          int64_t lda, int64_t ldw, int64_t ldc, int32_t epilogue, void* stream) {
+                          int64_t lda, int64_t ldw, int64_t ldc, int32_t epilogue, const int32_t* a_exp, const int32_t* w_exp, int32_t* status,
+                          void* stream) {
     if (M <= 0) return D3D_OK;
     if (N % 4 != 0 || K % XBK != 0 || K <= 0 || (lda & 3) || (ldw & 3) || (ldc & 3)) {
         d3d_set_error_("d3d_gemm_nt_f32x3: need N % 4 == 0, K % 32 == 0 (zero-pad), lda / ldw / ldc % 4 == 0");
@@ -206,9 +271,9 @@ int32_t d3d_gemm_nt_f32x3(const float* A, const float* W, float* C, const float*
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 2 * 128 * XPITCH * sizeof(_Float16))); \
             attr_err = once;                                                                                                        \
             if (attr_err == hipSuccess)                                                                                             \
-                hipLaunchKernelGGL((k_gemm_f32x3<E, 4>), grid, block, sh, s, A, W, C, bias, residual, M, N, K, lda, ldw, ldc, tm, tn); \
+                hipLaunchKernelGGL((k_gemm_f32x3<E, 4>), grid, block, sh, s, A, W, C, bias, residual, M, N, K, lda, ldw, ldc, tm, tn, a_exp, w_exp, status); \
         } else {                                                                                                                    \
-            hipLaunchKernelGGL((k_gemm_f32x3<E, 2>), grid, block, sh, s, A, W, C, bias, residual, M, N, K, lda, ldw, ldc, tm, tn);  \
+            hipLaunchKernelGGL((k_gemm_f32x3<E, 2>), grid, block, sh, s, A, W, C, bias, residual, M, N, K, lda, ldw, ldc, tm, tn, a_exp, w_exp, status);  \
         }                                                                                                                           \
         break;
     switch (epilogue) {

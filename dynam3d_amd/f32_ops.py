@@ -13,7 +13,8 @@ from . import _lib
 from ._lib import f32, i32, i64, vp
 
 _lib.register("d3d_gemm_nt_f32", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp])
-_lib.register("d3d_gemm_nt_f32x3", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp])
+_lib.register("d3d_gemm_nt_f32x3", [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp, vp, vp, vp])
+_lib.register("d3d_row_exponents", [vp, i32, i32, i64, vp, vp, vp])
 _lib.register("d3d_linear_smallk_f32", [vp, vp, vp, vp, i32, i32, i32, i64, i64, i32, vp])
 _lib.register("d3d_linear_smalln_f32", [vp, vp, vp, vp, i32, i32, i32, i64, i64, vp])
 _lib.register("d3d_layer_norm_f32", [vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, f32, i32, vp])
@@ -32,18 +33,76 @@ def _stream():
 class F32Ops:
     # The float32 GEMMs run as split-precision fp16 MFMAs (hi hi + hi lo + lo hi, float32 accumulation: csrc/f32x3_kernels.hip) --
     # float32 accuracy at 16-bit matrix rate.  D3D_F32_SPLIT=0 (or F32Ops.SPLIT = False) selects the v_mfma_f32_16x16x4_f32 kernel.
-    # RANGE CONTRACT of the split kernel: |operand| < 65504 (the hi half is an fp16), and an element below ~2^-13 keeps only its hi half
-    # (its lo half falls into fp16's subnormals): absolute error <= 2^-25 per such element, invisible next to O(1) elements of the same
-    # dot product -- which is what the token builder feeds it (LayerNorm'ed activations, unit-norm CLIP features, metres).  D3D_F32_CHECK=1
-    # (or F32Ops.CHECK = True; on in the golden-trajectory GPU tests) verifies every output of the split kernel to be finite -- a host
-    # synchronisation per GEMM, so a debug switch, not the default.
+    # RANGE of the split kernel (round 5): every operand ROW is scaled by a power of two so that its largest element lies in [1, 2) before the
+    # hi / lo split (`d3d_row_exponents`: once per weight -- cached next to the padded copy --, one small launch per call for the
+    # activations) and the result is scaled back: no finite row overflows fp16, a row of uniformly tiny values keeps its 22 bits; inside
+    # one row an element below 2^-14 of the row's maximum keeps only its hi half (absolute error <= 2^-25 x row max: invisible next to
+    # the leading terms of the same dot product).  SCALE = False (D3D_F32_SCALE=0) is the unscaled round-3 kernel (|operand| < 65504).
+    # A DEVICE status word collects "non-finite output" (bit 0) / "non-finite activation" (bit 1) from every launch with no host
+    # synchronisation; `poll_status()` reads the copy the previous `snapshot_status()` started (the token builder: snapshot at the end
+    # of an update, poll at the start of the next -- a bad GEMM is reported one step late, for free), `check_status()` synchronises.
+    # D3D_F32_CHECK=1 (F32Ops.CHECK; on in the golden-trajectory GPU tests) checks every GEMM at once: a host synchronisation per call.
     SPLIT = os.environ.get("D3D_F32_SPLIT", "1") != "0"
+    SCALE = os.environ.get("D3D_F32_SCALE", "1") != "0"
     CHECK = os.environ.get("D3D_F32_CHECK", "0") == "1"
     KPAD = 32                                        # both kernels take K % 32 == 0 (the float32 one needs 16)
 
     def __init__(self):
         self.lib = _lib.load()
         self._padded: Dict[tuple, torch.Tensor] = {}
+        self._wexp: Dict[int, tuple] = {}
+        self._status = None                          # device int32[1]
+        self._status_host = None                     # pinned int32[1]: the last snapshot
+        self._snap_event = None
+
+    # ---- device status word ----------------------------------------------------------------------------------------------------------
+    def _status_word(self, device) -> torch.Tensor:
+        if self._status is None or self._status.device != device:
+            self._status = torch.zeros(1, dtype=torch.int32, device=device)
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._snap_event = None
+        return self._status
+
+    def snapshot_status(self):
+        """Start an asynchronous copy of the status word to pinned host memory (no synchronisation)."""
+        if self._status is None:
+            return
+        self._status_host.copy_(self._status, non_blocking=True)
+        self._snap_event = torch.cuda.Event()
+        self._snap_event.record()
+
+    def poll_status(self):
+        """Raise if the last snapshot (when it has landed) recorded a non-finite float32 GEMM.  Never waits."""
+        if self._snap_event is None or not self._snap_event.query():
+            return
+        self._snap_event = None
+        self._raise_if(int(self._status_host[0]))
+
+    def check_status(self):
+        """Synchronising check (tests, end of an episode)."""
+        if self._status is not None:
+            self._raise_if(int(self._status.cpu()[0]))
+
+    def _raise_if(self, bits: int):
+        if bits:
+            self._status.zero_()
+            raise FloatingPointError("float32 token-builder GEMM (d3d_gemm_nt_f32x3): " + ", ".join(
+                m for b, m in ((1, "a non-finite output element"), (2, "a non-finite activation element")) if bits & b)
+                + " since the last check; D3D_F32_CHECK=1 locates the call, D3D_F32_SPLIT=0 selects the float32-MFMA kernel")
+
+    def row_exponents(self, x: torch.Tensor, status=None) -> torch.Tensor:
+        M, K = x.shape
+        out = torch.empty((M,), dtype=torch.int32, device=x.device)
+        _lib.check(self.lib.d3d_row_exponents(_p(x), M, K, x.stride(0), _p(out), _p(status), _stream()))
+        return out
+
+    def weight_exponents(self, wp: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """Row exponents of a (padded) weight, cached on the source tensor's storage + version like the padded copy."""
+        key, tag = w.data_ptr(), (w._version, tuple(wp.shape))
+        hit = self._wexp.get(key)
+        if hit is None or hit[0] != tag:
+            hit = self._wexp[key] = (tag, self.row_exponents(wp))
+        return hit[1]
 
     def prep_weight(self, w: torch.Tensor) -> torch.Tensor:
         """(N, K) float32 contiguous; K zero-padded to a multiple of 32 for the MFMA kernels (cached per tensor)."""
@@ -91,11 +150,19 @@ class F32Ops:
             epi = "bias_res"
         else:
             epi = "bias_gelu" if act == "gelu" else "bias"
-        gemm = self.lib.d3d_gemm_nt_f32x3 if self.SPLIT else self.lib.d3d_gemm_nt_f32
-        _lib.check(gemm(_p(x), _p(wp), _p(y), _p(b), _p(residual), M, N, Kp, x.stride(0), Kp, N, EPI[epi], _stream()))
-        if self.CHECK and self.SPLIT and not bool(torch.isfinite(y).all()):
+        if not self.SPLIT:
+            _lib.check(self.lib.d3d_gemm_nt_f32(_p(x), _p(wp), _p(y), _p(b), _p(residual), M, N, Kp, x.stride(0), Kp, N, EPI[epi], _stream()))
+            return y
+        st = self._status_word(x.device)
+        ea = ew = None
+        if self.SCALE:
+            ew = self.weight_exponents(wp, w)
+            ea = self.row_exponents(x, st)
+        _lib.check(self.lib.d3d_gemm_nt_f32x3(_p(x), _p(wp), _p(y), _p(b), _p(residual), M, N, Kp, x.stride(0), Kp, N, EPI[epi], _p(ea), _p(ew), _p(st),
+                                              _stream()))
+        if self.CHECK and not bool(torch.isfinite(y).all()):
             raise FloatingPointError(f"d3d_gemm_nt_f32x3: non-finite output for x {tuple(x.shape)} (max |x| {float(x.abs().max()):.3g}), w {tuple(w.shape)} "
-                                     f"(max |w| {float(w.abs().max()):.3g}): operands outside the split kernel's fp16 range; set D3D_F32_SPLIT=0")
+                                     f"(max |w| {float(w.abs().max()):.3g}); set D3D_F32_SPLIT=0 for the float32-MFMA kernel")
         return y
 
     def layer_norm(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None, gelu: bool = False) -> torch.Tensor:

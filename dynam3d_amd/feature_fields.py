@@ -414,10 +414,28 @@ class Feature_Fields(RefreshOnChange):
 
     # ---- update_feature_fields (VLN-FF:493-815) ------------------------------------------------------------
     @torch.no_grad()
-    def update_feature_fields(self, batch_depth, batch_grid_ft, batch_image=None, batch_position=None, batch_heading=None,
-                              batch_camera_intrinsic=None, batch_rot=None, batch_trans=None, depth_scale=1000.0,
-                              depth_trunc=1000.0, num_of_views=1, patch_segm=None, view_ids=None, batch_image_ft=None,
-                              is_training=False, trainer=None):
+    def update_feature_fields(self, *args, **kw):
+        """`_update_feature_fields` between two looks at the float32 GEMMs' DEVICE status word (f32_ops.F32Ops): the copy started at the end
+        of the previous update is examined (it has landed long ago: no wait), a new one is started behind this update's launches -- a
+        non-finite token-builder GEMM raises FloatingPointError one update late, with no host synchronisation on the step's path."""
+        f32 = self.dense._f32ops if (self.dense is not None and self.device.type == "cuda") else None
+        if f32 is not None:
+            f32.poll_status()
+        out = self._update_feature_fields(*args, **kw)
+        f32 = self.dense._f32ops if (self.dense is not None and self.device.type == "cuda") else None
+        if f32 is not None:
+            f32.snapshot_status()
+        return out
+
+    def check_numerics(self):
+        """Synchronising form of the same check (end of an episode, tests)."""
+        if self.dense is not None and self.dense._f32ops is not None:
+            self.dense._f32ops.check_status()
+
+    def _update_feature_fields(self, batch_depth, batch_grid_ft, batch_image=None, batch_position=None, batch_heading=None,
+                               batch_camera_intrinsic=None, batch_rot=None, batch_trans=None, depth_scale=1000.0,
+                               depth_trunc=1000.0, num_of_views=1, patch_segm=None, view_ids=None, batch_image_ft=None,
+                               is_training=False, trainer=None):
         """`num_of_views` (VLN-FF:493: view ix at heading - ix*pi/6) or `view_ids` (PRE-FF:843,920: view ix at
         heading - view_ids[ix]*pi/6, e.g. [0,3,6,9] = the four 90-degree views of `Net_3DFF.forward`, PRE-POL:160)."""
         if is_training and trainer is None:

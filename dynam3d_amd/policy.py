@@ -184,6 +184,7 @@ class Dynam3D_VLN(RefreshOnChange):
         self.pano_angle_fts = torch.stack([torch.sin(ang), torch.cos(ang), torch.sin(torch.zeros_like(ang)), torch.cos(torch.zeros_like(ang))], 1).float()
         self.tokenizer = tokenizer or SyntheticTokenizer(cfg.llm.vocab)
         self.last_lengths = None
+        self.keep_prompt, self.last_prompt = False, None
         self._mlp_sig = None
         self._init_refresh_hooks()
         self.refresh()
@@ -459,6 +460,8 @@ class Dynam3D_VLN(RefreshOnChange):
         if self.llm.packed_ok():
             x, lengths = self.build_inputs(observations, instructions, agent_positions, agent_heading_angles, depth_scale,
                                            delete_old_features, num_of_views, patch_segm, return_rows="packed")
+            if self.keep_prompt:                             # (bench.py's parity block: the packed rows handed to Phi-3; the prefill does not write them)
+                self.last_prompt = (x, list(lengths))
             return self.llm.prefill_logits_packed(x, lengths)
         rows, _ = self.build_inputs(observations, instructions, agent_positions, agent_heading_angles, depth_scale,
                                     delete_old_features, num_of_views, patch_segm, return_rows=True)

@@ -278,9 +278,17 @@ int32_t d3d_gemm_nt_f32(const float* A_d, const float* W_d, float* C_d, const fl
                         int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t epilogue, void* stream);
 /* Same contract, on the 16-bit matrix cores at float32 accuracy: each float32 element is split into fp16 hi + lo while its tile is
  * staged and the product taken as three fp16 MFMAs (hi hi + hi lo + lo hi) with float32 accumulation -- ~1e-6 relative to a float32
- * GEMM, 5.3x its matrix peak (csrc/f32x3_kernels.hip).  K % 32 == 0; |operand| < 65504.  The inference token builder's default. */
+ * GEMM, 5.3x its matrix peak (csrc/f32x3_kernels.hip).  K % 32 == 0.  The inference token builder's default.
+ * a_exp_d (M) / w_exp_d (N), nullable: per-row exponents from d3d_row_exponents -- every operand row is scaled by 2^-exp (exact) before
+ * the split and the result scaled back, so no finite row overflows or underflows fp16 (without them: |operand| < 65504 and a row of
+ * uniformly tiny values loses bits).  status_d (nullable): bit 0 is OR-ed in when an output element is not finite; the library never
+ * reads or clears it. */
 int32_t d3d_gemm_nt_f32x3(const float* A_d, const float* W_d, float* C_d, const float* bias_d, const float* residual_d, int32_t M, int32_t N,
-                          int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t epilogue, void* stream);
+                          int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t epilogue, const int32_t* a_exp_d, const int32_t* w_exp_d,
+                          int32_t* status_d, void* stream);
+/* out_d[m] = floor(log2(max |X[m, :]|)) (0 for a zero row, clamped to +-100); a non-finite element ORs bit 1 into status_d (nullable) and
+ * is left out of the maximum.  X (M, K) float32, K % 4 == 0, ld % 4 == 0. */
+int32_t d3d_row_exponents(const float* X_d, int32_t M, int32_t K, int64_t ld, int32_t* out_d, int32_t* status_d, void* stream);
 /* y = [gelu](x W^T + b) for 1 <= K <= 8 (geometry inputs of the position-embedding MLPs; W (N,K) contiguous) */
 int32_t d3d_linear_smallk_f32(const float* x_d, const float* W_d, const float* bias_d, float* y_d, int32_t M, int32_t N, int32_t K, int64_t ldx,
                               int64_t ldy, int32_t gelu, void* stream);

@@ -72,5 +72,82 @@ def test_split_gemm_refuses_bad_shapes():
     w = torch.zeros(64, 48, device="cuda")
     y = torch.zeros(64, 64, device="cuda")
     rc = lib.d3d_gemm_nt_f32x3(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(y.data_ptr()), None, None, 64, 64, 48, 48, 48, 64, 0,
-                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                               None, None, None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc != 0                                                      # K % 32 != 0
+
+
+def test_row_scaling_removes_the_fp16_range_contract():
+    """Operands spanning 1e-6 .. 1e3 ACROSS rows, far beyond fp16 on both sides: rows of ~1e5 (the unscaled kernel: inf), rows of ~1e-6
+    (the unscaled kernel: fp16 subnormals, a few bits) and rows mixing 1e-6 .. 1e3 -- against float64, error relative to sum|terms|."""
+    torch.manual_seed(11)
+    M, N, K = 640, 768, 768
+    x = torch.randn(M, K, device="cuda")
+    x[:128] *= 3e5                                                    # beyond 65504
+    x[128:256] *= 1e-6                                                # uniformly tiny rows
+    x[256:384] *= torch.pow(10.0, torch.empty(128, K, device="cuda").uniform_(-6, 3))
+    w = torch.randn(N, K, device="cuda") * K ** -0.5
+    w[:64] *= 1e4
+    w[64:128] *= 1e-5
+    b = torch.zeros(N, device="cuda")
+    ref = x.double() @ w.double().t()
+    scale = x.double().abs() @ w.double().abs().t()
+    x3 = _ops(True)
+    y = x3.linear(x, w, b).double()
+    x3.check_status()                                                 # nothing non-finite
+    assert bool(torch.isfinite(y).all())
+    e = float(((y - ref).abs() / scale).max())
+    y32 = _ops(False).linear(x, w, b).double()
+    e32 = float(((y32 - ref).abs() / scale).max())
+    print(f"scaled split kernel, rows from 1e-6 to 3e5: max |err| / sum|terms| {e:.2e} (float32-MFMA kernel {e32:.2e})")
+    assert e < 1e-6, e
+    un = _ops(True)
+    un.SCALE = False
+    yu = un.linear(x, w, b)
+    assert not bool(torch.isfinite(yu[:128]).all())                   # the round-3 kernel: rows beyond fp16 overflow ...
+    import pytest as _pt
+    with _pt.raises(FloatingPointError):
+        un.check_status()                                             # ... and the device status word says so
+    eu = float(((yu[128:256].double() - ref[128:256]).abs() / scale[128:256]).max())
+    es = float(((y[128:256] - ref[128:256]).abs() / scale[128:256]).max())
+    print(f"uniformly tiny rows: unscaled {eu:.2e}, scaled {es:.2e}")
+    assert es < 1e-6 < eu
+
+
+def test_one_ulp_apart_inputs_keep_their_order_and_ties_stay_ties():
+    """Merge-discriminator input rows one float32 ulp apart in one element.  Identical rows give identical bits (a tie in float32 stays
+    a tie: the kernel is a fixed-order sum).  A +1 ulp input moves an output in the direction of its weight or not at all -- the hi + lo
+    representation is monotone in x; the one exception is a step that carries from lo into hi (probability ~2^-13 per element), where
+    the dropped a_lo w_lo term jumps by <= 2^-22 |a w|: float32 summation-order size, bounded below."""
+    torch.manual_seed(5)
+    K, N = 1568, 3072
+    w = torch.randn(N, K, device="cuda") * K ** -0.5
+    b = torch.zeros(N, device="cuda")
+    base = torch.randn(1, K, device="cuda")
+    rows = base.repeat(257, 1)
+    idx = torch.arange(256, device="cuda") * 6
+    up = torch.nextafter(base[0, idx], torch.full_like(base[0, idx], float("inf")))
+    rows[torch.arange(256, device="cuda") + 1, idx] = up              # row r + 1 = base with element idx[r] one ulp up
+    x3 = _ops(True)
+    y = x3.linear(rows, w, b)
+    twin = x3.linear(torch.cat([base, base], 0), w, b)
+    assert torch.equal(twin[0], twin[1]) and torch.equal(twin[0], y[0])
+    d = (y[1:] - y[:1]).double()                                      # (256, N): effect of +1 ulp in element idx[r]
+    sign_w = torch.sign(w[:, idx].t().double())                       # (256, N)
+    wrong = d * sign_w < 0
+    assert float(wrong.double().mean()) < 1e-3, float(wrong.double().mean())
+    bound = (base[0, idx].abs().double()[:, None] * w[:, idx].t().abs().double()) * 2.0 ** -21 + 1e-12
+    assert bool((d.abs() <= bound + y[:1].abs().double() * 2.0 ** -22).all())
+
+
+def test_status_word_is_polled_one_update_late_without_a_sync():
+    x3 = _ops(True)
+    x = torch.randn(64, 768, device="cuda")
+    x[3, 5] = float("nan")
+    w = torch.randn(768, 768, device="cuda")
+    x3.linear(x, w, torch.zeros(768, device="cuda"))
+    x3.snapshot_status()
+    torch.cuda.synchronize()
+    import pytest as _pt
+    with _pt.raises(FloatingPointError):
+        x3.poll_status()
+    x3.poll_status()                                                  # cleared

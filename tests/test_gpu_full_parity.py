@@ -4,7 +4,7 @@ tokens).  Everything the piecewise tests cover separately -- towers, per-layer t
 composed once at full size: RGB-D in, logits / generated tokens out (VLN-POL:329-363, 430-463).
 
 Criterion for the 16-bit logits = the noise band: g19 carries the distance between the reference-dtype evaluation and
-float32; the HIP path must be within 1.25 x that band of BOTH, choose the oracle's token wherever the oracle's own top-2 margin is
+float32; the HIP path must be within that band of the lowp oracle (hard) and within 1.05 x it of float32, choose the oracle's token wherever the oracle's own top-2 margin is
 outside the band, and overlap its top-5.  Bookkeeping (prompt lengths, instance / zone counts) is exact."""
 import os
 
@@ -63,7 +63,9 @@ def test_full_configuration_step_and_generation_vs_oracle_golden():
             assert net.last_counts["Ni"] == g[f"ni_{t}"].tolist() and net.last_counts["Nz"] == g[f"nz_{t}"].tolist()
             band = _rel(lowp, f32)
             d32, d16 = _rel(lo, f32), _rel(lo, lowp)
-            assert d32 < 1.25 * band and d16 < 1.25 * band, (t, d32, d16, band)
+            # hard: the HIP evaluation is at least as close to the reference-dtype (lowp) oracle as float32 is; its own distance from float32
+            # is one more sample of the same 16-bit noise (measured 1.74e-2 / 1.73e-2 against the band's 1.73e-2): 5 % sampling slack
+            assert d16 <= band and d32 <= 1.05 * band, (t, d32, d16, band)
             srt = np.sort(f32, -1)
             margin = (srt[:, -1] - srt[:, -2]) / np.sqrt((f32.astype(np.float64) ** 2).mean(-1))
             top5 = []
