@@ -710,7 +710,21 @@ int32_t launch(const void* A, const void* W, void* C, const void* bias, const vo
 // the <= 16 rows once into LDS (wave per row, the lane / chunk order of k_norm: bit-identical to d3d_norm) while its first weight
 // fragments are in flight, and the K loop reads its activation fragments from there.  Saves the d3d_norm launch in front of the
 // qkv / gate_up / lm_head projections of a decode token (64 + 1 launches of ~7 us each per token).
-template <bool BF16, int EPI, bool HALF, bool NORM = false>
+// NT: the weight stream is loaded non-temporally (global_load_dwordx4 ... nt): every weight byte is read by ONE workgroup ONCE per token, so
+// keeping it out of the caches' replacement order leaves them to the activations and the KV cache (MI355X_MICROARCH.md "nt-weights":
+// 5-10 % per decode layer).  Runtime choice D3D_SKINNY_NT (launch_skinny).
+template <bool NT>
+__device__ __forceinline__ uint4 ld_weight(const uint16_t* p) {
+    if constexpr (NT) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    } else {
+        return *reinterpret_cast<const uint4*>(p);
+    }
+}
+
+template <bool BF16, int EPI, bool HALF, bool NORM = false, bool NT = false>
 __global__ void __launch_bounds__(1024)
 k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, uint16_t* __restrict__ C, const uint16_t* __restrict__ bias,
               const uint16_t* __restrict__ residual, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldc,
@@ -731,8 +745,8 @@ k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, ui
     if (first) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            a[u] = *reinterpret_cast<const uint4*>(w0 + (st + u) * 32);
-            if constexpr (!HALF) b[u] = *reinterpret_cast<const uint4*>(w1 + (st + u) * 32);
+            a[u] = ld_weight<NT>(w0 + (st + u) * 32);
+            if constexpr (!HALF) b[u] = ld_weight<NT>(w1 + (st + u) * 32);
         }
     }
     const int xrow = fi < M ? fi : M - 1;                                           // rows >= M: a duplicate, never stored
@@ -793,8 +807,8 @@ k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, ui
             if (more) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    an[u] = *reinterpret_cast<const uint4*>(w0 + (st + 4 + u) * 32);
-                    if constexpr (!HALF) bn[u] = *reinterpret_cast<const uint4*>(w1 + (st + 4 + u) * 32);
+                    an[u] = ld_weight<NT>(w0 + (st + 4 + u) * 32);
+                    if constexpr (!HALF) bn[u] = ld_weight<NT>(w1 + (st + 4 + u) * 32);
                 }
             }
 #pragma unroll
@@ -812,11 +826,11 @@ k_gemm_skinny(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W, ui
         }
     }
     for (; st < s1; ++st) {
-        const uint4 aw = *reinterpret_cast<const uint4*>(w0 + st * 32);
+        const uint4 aw = ld_weight<NT>(w0 + st * 32);
         const uint4 x = xfrag(st);
         acc0 = mfma16<BF16>(aw, x, acc0);
         if constexpr (!HALF) {
-            const uint4 bw = *reinterpret_cast<const uint4*>(w1 + st * 32);
+            const uint4 bw = ld_weight<NT>(w1 + st * 32);
             acc1 = mfma16<BF16>(bw, x, acc1);
         }
     }
@@ -858,21 +872,30 @@ int32_t launch_skinny(const void* A, const void* W, void* C, const void* bias, c
         static std::once_flag attr_once;
         static hipError_t attr_err = hipSuccess;
         std::call_once(attr_once, [&] {
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<BF16, EPI, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if constexpr (EPI != EPI_SWIGLU)
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<BF16, EPI, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (attr_err == hipSuccess)
+                attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<BF16, EPI, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if constexpr (EPI != EPI_SWIGLU) {
                 if (attr_err == hipSuccess)
-                    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<BF16, EPI, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<BF16, EPI, true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (attr_err == hipSuccess)
+                    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<BF16, EPI, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
         });
         D3D_HIP(attr_err);
     }
+    static const bool nt = [] { const char* e = getenv("D3D_SKINNY_NT"); return !(e && e[0] == '0'); }();       // non-temporal weight loads (default on)
+#define D3D_SKINNY_LAUNCH(HALFV, NTV)                                                                                                    \
+    hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, HALFV, NORM, NTV>), dim3(ntiles), dim3(nwv * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W, \
+                       (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, nw, eps)
     if (half) {
-        if constexpr (EPI != EPI_SWIGLU)
-            hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, true, NORM>), dim3(ntiles), dim3(nwv * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,
-                               (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, nw, eps);
+        if constexpr (EPI != EPI_SWIGLU) {
+            if (nt) D3D_SKINNY_LAUNCH(true, true); else D3D_SKINNY_LAUNCH(true, false);
+        }
     } else {
-        hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, false, NORM>), dim3(ntiles), dim3(nwv * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W,
-                           (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, nw, eps);
+        if (nt) D3D_SKINNY_LAUNCH(false, true); else D3D_SKINNY_LAUNCH(false, false);
     }
+#undef D3D_SKINNY_LAUNCH
     D3D_LAUNCH_CHECK();
 }
 

@@ -35,4 +35,5 @@ for s in range(first_timed, n_steps_total):
         tot_ns += (t1 - t0) + td
         tot_fl += 2.0 * tk * 3072 * 16384
 print(f"# launches {steps * per_step}; sum FLOP {tot_fl:.6e}; sum duration {tot_ns:.0f} ns; achieved {tot_fl / tot_ns / 1e3:.1f} TFLOP/s = {tot_fl / tot_ns / 1e3 / 2500:.4f} of 2.5 PF "
-      f"(PROFILED run: rocprofv3 serialises the launches, the chip runs cooler and clocks higher than in the un-profiled benchmark; bench.py reports the un-profiled HIP-event figure)")
+      f"(PROFILED run; bench.py reports the un-profiled HIP-event figure.  The two differ by box and by clock: round 4's profiled run was the SLOWER one -- "
+      f"0.507 here against 0.542 from HIP events on another box, PMC shader clock 1.74-1.76 GHz -- so no direction is claimed; compare runs of ONE gpurun call)")
