@@ -240,6 +240,146 @@ k_decode_attn(const uint16_t* __restrict__ qkv_new /* (B, 3H, HD): this step's r
     if (tid == 0) __hip_atomic_store(counters + b * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this stream
 }
 
+// ================================================================================================
+// Decode attention, second kernel (round 5): ONE pass over the keys with an online softmax, coalesced K / V rows.
+//
+// k_decode_attn above makes three dependent sweeps -- thread-per-key scores (a wave instruction touches 64 different rows, 16 bytes of
+// each), a block softmax in LDS, then the value sum -- so the value rows are requested only after two block-wide reductions, with four
+// waves per CU in flight: 29-31 us for 85 MB (2.8 TB/s), ~8 us of it the latency chain.  Here a key row is read by LPK consecutive lanes
+// (16 bytes each: one 192-byte row = one contiguous segment), its K and V rows are requested TOGETHER, U keys per lane group are in
+// flight before the first is used, and every lane group keeps its own running (max, sum, output) -- no synchronisation inside the
+// sweep.  NWV waves per workgroup; the (NWV x KPW) partial states meet once in LDS and are merged in a fixed order (deterministic).
+// Same arithmetic as k_decode_attn (float32 scores, probabilities and sums; RoPE of the new q / k as in k_rope), another summation order.
+// ================================================================================================
+template <bool BF16, int HD, int NWV, int U = 4>
+__global__ void __launch_bounds__(NWV * 64)
+k_decode_attn2(const uint16_t* __restrict__ qkv_new, const uint16_t* __restrict__ prompt, const int32_t* __restrict__ cu, uint16_t* __restrict__ knew,
+               uint16_t* __restrict__ vnew, uint16_t* __restrict__ out, int H, int t_new, int Tmax, float scale, const float* __restrict__ cos_t,
+               const float* __restrict__ sin_t, const int32_t* __restrict__ pos) {
+    constexpr int CH = HD / 8;                          // 16-byte chunks per row: 12 / 8
+    constexpr int LPK = CH <= 8 ? 8 : 16;               // lanes per key
+    constexpr int KPW = 64 / LPK;                       // keys per wave instruction: 8 / 4
+    // U = keys in flight per lane group
+    constexpr int NP = NWV * KPW;                       // partial softmax states per workgroup
+    __shared__ float qs[HD];
+    __shared__ __attribute__((aligned(16))) uint16_t kcur[HD];
+    __shared__ float po[NP][HD];
+    __shared__ float pm[NP], pl[NP];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t rs = (int64_t)3 * H * HD;
+    const int r0 = cu[b], S = cu[b + 1] - r0, L = S + t_new + 1;
+    const uint16_t* qrow = qkv_new + (int64_t)b * rs + (int64_t)h * HD;
+    constexpr int HALF = HD / 2;
+    if (tid < HALF) {                                   // (the prologue of k_decode_attn: RoPE of this token's q and k, side-cache append)
+        float q1 = cvt16<BF16>(qrow[tid]), q2 = cvt16<BF16>(qrow[tid + HALF]);
+        float k1 = cvt16<BF16>(qrow[(int64_t)H * HD + tid]), k2 = cvt16<BF16>(qrow[(int64_t)H * HD + tid + HALF]);
+        uint16_t kr1, kr2;
+        if (cos_t) {
+            const float c = cos_t[(int64_t)pos[b] * HALF + tid], sn = sin_t[(int64_t)pos[b] * HALF + tid];
+            auto r = [](float f) { return cvt16<BF16>((uint16_t)pack2<BF16>(f, 0.f)); };
+            const uint32_t qp = pack2<BF16>(r(q1 * c) - r(q2 * sn), r(q2 * c) + r(q1 * sn));
+            const uint32_t kp2 = pack2<BF16>(r(k1 * c) - r(k2 * sn), r(k2 * c) + r(k1 * sn));
+            q1 = cvt16<BF16>((uint16_t)qp);
+            q2 = cvt16<BF16>((uint16_t)(qp >> 16));
+            kr1 = (uint16_t)kp2;
+            kr2 = (uint16_t)(kp2 >> 16);
+        } else {
+            kr1 = qrow[(int64_t)H * HD + tid];
+            kr2 = qrow[(int64_t)H * HD + tid + HALF];
+        }
+        qs[tid] = q1 * scale;
+        qs[tid + HALF] = q2 * scale;
+        kcur[tid] = kr1;
+        kcur[tid + HALF] = kr2;
+        uint16_t* kd = knew + (((int64_t)b * Tmax + t_new) * H + h) * HD;
+        kd[tid] = kr1;
+        kd[tid + HALF] = kr2;
+    } else if (tid >= 64 && tid < 64 + HD / 8) {
+        const int c = tid - 64;
+        const uint4 v = *reinterpret_cast<const uint4*>(qrow + (int64_t)2 * H * HD + c * 8);
+        *reinterpret_cast<uint4*>(vnew + (((int64_t)b * Tmax + t_new) * H + h) * HD + c * 8) = v;
+    }
+    __syncthreads();
+    const int g = lane / LPK, c = lane % LPK;
+    const bool lane_on = c < CH;
+    const int cc = lane_on ? c : 0;                     // (idle lanes of a 16-lane group re-read chunk 0: their products are zeroed)
+    float q[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) q[d] = lane_on ? qs[cc * 8 + d] : 0.f;
+    float m = -INFINITY, l = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto dot8 = [&](const uint4& kv) -> float {
+        const uint16_t* e = reinterpret_cast<const uint16_t*>(&kv);
+        float s0 = q[0] * cvt16<BF16>(e[0]) + q[4] * cvt16<BF16>(e[4]);
+        float s1 = q[1] * cvt16<BF16>(e[1]) + q[5] * cvt16<BF16>(e[5]);
+        float s2 = q[2] * cvt16<BF16>(e[2]) + q[6] * cvt16<BF16>(e[6]);
+        float s3 = q[3] * cvt16<BF16>(e[3]) + q[7] * cvt16<BF16>(e[7]);
+        float sdot = (s0 + s1) + (s2 + s3);
+#pragma unroll
+        for (int w = LPK / 2; w >= 1; w >>= 1) sdot += __shfl_xor(sdot, w, 64);       // the LPK lanes of one key
+        return sdot;
+    };
+    auto fold = [&](float sc_, const uint4& vv, bool valid) {                            // one key into this lane group's running state
+        if (!valid) return;
+        const float m_new = fmaxf(m, sc_);
+        const float alpha = __expf(m - m_new);          // (m = -inf at the first key: exp(-inf) = 0)
+        const float p = __expf(sc_ - m_new);
+        l = l * alpha + p;
+        const uint16_t* e = reinterpret_cast<const uint16_t*>(&vv);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o[d] = o[d] * alpha + p * cvt16<BF16>(e[d]);
+        m = m_new;
+    };
+    // ---- prompt keys: rows r0 .. r0 + S of the layer's prefill buffer, read in place -------------------------------------------------------
+    const uint16_t* kbase = prompt + (int64_t)r0 * rs + (int64_t)(H + h) * HD + cc * 8;
+    const uint16_t* vbase = prompt + (int64_t)r0 * rs + (int64_t)(2 * H + h) * HD + cc * 8;
+    int j = wave * KPW + g;
+    for (; j + (U - 1) * NP < S; j += U * NP) {
+        uint4 kk[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            kk[u] = *reinterpret_cast<const uint4*>(kbase + (int64_t)(j + u * NP) * rs);
+            vv[u] = *reinterpret_cast<const uint4*>(vbase + (int64_t)(j + u * NP) * rs);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) fold(dot8(kk[u]), vv[u], true);
+    }
+    for (; j < S; j += NP) {                             // (the shuffles of dot8 need the whole lane group: j is uniform inside it)
+        const uint4 kk = *reinterpret_cast<const uint4*>(kbase + (int64_t)j * rs);
+        const uint4 vv = *reinterpret_cast<const uint4*>(vbase + (int64_t)j * rs);
+        fold(dot8(kk), vv, true);
+    }
+    // ---- generated tokens (side cache, written by EARLIER launches) and the current one (LDS / qkv_new: nothing this launch wrote is read back)
+    for (int jt = S + wave * KPW + g; jt < L; jt += NP) {
+        const bool cur = jt == L - 1;
+        const uint16_t* kp = knew + (((int64_t)b * Tmax + (jt - S)) * H + h) * HD + cc * 8;
+        const uint16_t* vp = cur ? qrow + (int64_t)2 * H * HD + cc * 8 : vnew + (((int64_t)b * Tmax + (jt - S)) * H + h) * HD + cc * 8;
+        const uint4 kk = cur ? *reinterpret_cast<const uint4*>(kcur + cc * 8) : *reinterpret_cast<const uint4*>(kp);
+        const uint4 vv = *reinterpret_cast<const uint4*>(vp);
+        fold(dot8(kk), vv, true);
+    }
+    // ---- merge the NP partial states in a fixed order ----------------------------------------------------------------------------------------
+    const int ps = wave * KPW + g;
+    if (lane_on) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) po[ps][c * 8 + d] = o[d];
+    }
+    if (c == 0) { pm[ps] = m; pl[ps] = l; }
+    __syncthreads();
+    if (tid < HD / 2) {
+        float mx = -INFINITY;
+        for (int i = 0; i < NP; ++i) mx = fmaxf(mx, pm[i]);
+        float lt = 0.f, a0 = 0.f, a1 = 0.f;
+        for (int i = 0; i < NP; ++i) {
+            const float wgt = pm[i] == -INFINITY ? 0.f : __expf(pm[i] - mx);       // (a state that saw no key)
+            lt += pl[i] * wgt;
+            a0 += po[i][2 * tid] * wgt;
+            a1 += po[i][2 * tid + 1] * wgt;
+        }
+        const float il = 1.0f / lt;
+        *reinterpret_cast<uint32_t*>(out + ((int64_t)b * H + h) * HD + 2 * tid) = pack2<BF16>(a0 * il, a1 * il);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -285,6 +425,24 @@ int32_t d3d_decode_attention(const void* qkv_new, const void* prompt_qkv, const 
         part = (float*)((char*)e.first + (size_t)B * H * sizeof(unsigned));
     }
     const int fake_hm = getenv("D3D_DECODE_FAKE_HM") != nullptr;
+    // D3D_DECODE_ATTN: 2 (default) = the one-pass kernel k_decode_attn2 (nsplit 1 only), 1 = the three-sweep kernel above
+    const char* ae = getenv("D3D_DECODE_ATTN");                                // (read per call, like D3D_DECODE_SPLIT: the benchmarks sweep it)
+    const int attn_kernel = ae ? atoi(ae) : 2;
+    if (attn_kernel == 2 && nsplit == 1 && !fake_hm) {
+        // D3D_DECODE_ATTN2_CFG = waves per workgroup * 100 + keys in flight per lane group (tuning knob: 804 default, 1604, 808, 1608)
+        const char* ce = getenv("D3D_DECODE_ATTN2_CFG");
+        const int cfg2 = ce ? atoi(ce) : 804;
+        dim3 grid2(H, B);
+#define D3D_DEC2K(BF, HDV, NW_, U_) hipLaunchKernelGGL((k_decode_attn2<BF, HDV, NW_, U_>), grid2, dim3(NW_ * 64), 0, s, (const uint16_t*)qkv_new, (const uint16_t*)prompt_qkv, \
+                                             cu_seqlens, (uint16_t*)knew, (uint16_t*)vnew, (uint16_t*)out, H, t_new, Tmax, scale, cos_t, sin_t, pos)
+#define D3D_DEC2(BF, HDV) do { if (cfg2 == 1604) D3D_DEC2K(BF, HDV, 16, 4); else if (cfg2 == 808) D3D_DEC2K(BF, HDV, 8, 8); else if (cfg2 == 1608) D3D_DEC2K(BF, HDV, 16, 8); \
+                               else if (cfg2 == 404) D3D_DEC2K(BF, HDV, 4, 4); else D3D_DEC2K(BF, HDV, 8, 4); } while (0)
+        if (dtype == 0) { if (head_dim == 96) D3D_DEC2(true, 96); else D3D_DEC2(true, 64); }
+        else { if (head_dim == 96) D3D_DEC2(false, 96); else D3D_DEC2(false, 64); }
+#undef D3D_DEC2
+#undef D3D_DEC2K
+        D3D_LAUNCH_CHECK();
+    }
     dim3 grid(H, B, nsplit), block(256);
 #define D3D_DEC(BF, HDV) hipLaunchKernelGGL((k_decode_attn<BF, HDV>), grid, block, 0, s, (const uint16_t*)qkv_new, (const uint16_t*)prompt_qkv, cu_seqlens, \
                                             (uint16_t*)knew, (uint16_t*)vnew, (uint16_t*)out, H, t_new, Tmax, scale, cos_t, sin_t, pos, nsplit, part, counters, fake_hm)

@@ -710,9 +710,7 @@ int32_t launch(const void* A, const void* W, void* C, const void* bias, const vo
 // the <= 16 rows once into LDS (wave per row, the lane / chunk order of k_norm: bit-identical to d3d_norm) while its first weight
 // fragments are in flight, and the K loop reads its activation fragments from there.  Saves the d3d_norm launch in front of the
 // qkv / gate_up / lm_head projections of a decode token (64 + 1 launches of ~7 us each per token).
-// NT: the weight stream is loaded non-temporally (global_load_dwordx4 ... nt): every weight byte is read by ONE workgroup ONCE per token, so
-// keeping it out of the caches' replacement order leaves them to the activations and the KV cache (MI355X_MICROARCH.md "nt-weights":
-// 5-10 % per decode layer).  Runtime choice D3D_SKINNY_NT (launch_skinny).
+// NT: the weight stream loaded non-temporally (global_load_dwordx4 ... nt; MI355X_MICROARCH.md "nt-weights").  A knob, off by default: see launch_skinny.
 template <bool NT>
 __device__ __forceinline__ uint4 ld_weight(const uint16_t* p) {
     if constexpr (NT) {
@@ -884,7 +882,10 @@ int32_t launch_skinny(const void* A, const void* W, void* C, const void* bias, c
         });
         D3D_HIP(attr_err);
     }
-    static const bool nt = [] { const char* e = getenv("D3D_SKINNY_NT"); return !(e && e[0] == '0'); }();       // non-temporal weight loads (default on)
+    // non-temporal weight loads: OFF by default -- measured SLOWER here (profiles/r05_decode.txt: 3.11 -> 3.30 ms per token; this kernel's
+    // 16-row x 64-byte wave loads are not the guide's 1 KiB LDS-DMA stream).  D3D_SKINNY_NT=1 selects them (read per call: bench_decode.py).
+    const char* nte = getenv("D3D_SKINNY_NT");
+    const bool nt = nte && nte[0] == '1';
 #define D3D_SKINNY_LAUNCH(HALFV, NTV)                                                                                                    \
     hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, HALFV, NORM, NTV>), dim3(ntiles), dim3(nwv * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W, \
                        (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, nw, eps)

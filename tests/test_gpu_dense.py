@@ -374,15 +374,18 @@ def test_flash_attention_sliding_window(hd):
         assert rel(hd.attention_qkv(qkv, H, True, window=130).float(), ref) < tol
 
 
-@pytest.mark.parametrize("split", [None, "2"])
+@pytest.mark.parametrize("split", [None, "2", "attn1"])
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 6e-3), (torch.float16, 1e-3)])
 def test_decode_attention_kv_cache(hd, dt, tol, split, monkeypatch):
-    """(split = D3D_DECODE_SPLIT: the keys of a (sequence, head) cut into ranges whose partial softmax results the last workgroup
+    """(default: the one-pass kernel k_decode_attn2; "attn1" = D3D_DECODE_ATTN=1: the three-sweep kernel it replaced, kept as a knob;
+    split = D3D_DECODE_SPLIT: the keys of a (sequence, head) cut into ranges whose partial softmax results the last workgroup
     to finish merges -- off by default, kept as a tested knob.)
     d3d_decode_attention: one query per sequence over [prompt keys read in place from a packed QKV buffer | side cache | the
     current token], ragged prompts, several decode steps; vs fp32 softmax attention over the same (16-bit) keys and values.  The
     fused-RoPE form (un-rotated q, k + cos/sin/pos) must give what rope_inplace followed by the plain form gives."""
-    if split is not None:
+    if split == "attn1":
+        monkeypatch.setenv("D3D_DECODE_ATTN", "1")
+    elif split is not None:
         monkeypatch.setenv("D3D_DECODE_SPLIT", split)
     torch.manual_seed(6)
     H, d, Tmax = 4, 96, 5

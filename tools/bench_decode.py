@@ -46,6 +46,13 @@ modes = [("launch-per-op, 1 key range", {"D3D_DECODE_PERSISTENT": "0", "D3D_DECO
          ("persistent kernel", {"D3D_DECODE_PERSISTENT": "1"})]
 if os.environ.get("BENCH_DECODE_QUICK") == "1":
     modes = modes[4:8]
+if os.environ.get("BENCH_DECODE_R05") == "1":        # round 5: one-pass decode attention (D3D_DECODE_ATTN=2) and non-temporal weight loads (D3D_SKINNY_NT=1)
+    base = {"D3D_DECODE_PERSISTENT": "0", "D3D_DECODE_SPLIT": "1"}
+    modes = [(f"attention kernel {a}, weight loads {'nt' if n == '1' else 'default'}", dict(base, D3D_DECODE_ATTN=a, D3D_SKINNY_NT=n))
+             for _ in range(2) for a, n in (("1", "0"), ("2", "0"), ("1", "1"), ("2", "1"))]
+if os.environ.get("BENCH_DECODE_R05") == "2":        # one-pass attention: waves per workgroup x keys in flight
+    base = {"D3D_DECODE_PERSISTENT": "0", "D3D_DECODE_SPLIT": "1", "D3D_DECODE_ATTN": "2", "D3D_SKINNY_NT": "0"}
+    modes = [(f"one-pass attention, cfg {c}", dict(base, D3D_DECODE_ATTN2_CFG=c)) for _ in range(2) for c in ("804", "404", "1604", "808", "1608")]
 for name, env in modes:
     os.environ.pop("D3D_DECODE_SPLIT", None)
     os.environ.update(env)
