@@ -29,6 +29,7 @@ SIGNATURES = {
     "d3d_unproject_pinhole_append": [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i64, vp],
     "d3d_knn": [vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, vp, vp, vp],
     "d3d_knn_radius": [vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, f32, vp, vp, vp],
+    "d3d_knn_chunked": [vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "d3d_group_stats7": [vp, vp, vp, i64, vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, i64, vp],
     "d3d_group_stats4": [vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, i64, vp],
     "d3d_gather_fts": [vp, i64, vp, vp, i32, vp, vp],

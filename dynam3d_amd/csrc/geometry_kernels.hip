@@ -486,6 +486,123 @@ k_knn(const float* __restrict__ points, int64_t point_stride, const int32_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// KNN over LARGE point sets (the Pretrain GT instance cloud, PRE-FF:977-983: 1e5-1e6 points, k = 1, 576 queries per view): k_knn gives every
+// workgroup ALL points of its environment, so 4 608 queries x 2e5 points ran on 24 workgroups (6 ms).  Here blockIdx.z cuts the point range
+// into `n_chunks` pieces; every (query block, chunk) workgroup writes its own top-k -- same d^2 expression, same strict-less insertion --
+// and k_knn_merge folds the chunks in ascending chunk order with the same insertion, so equal distances still go to the lower index:
+// bit-identical to k_knn.
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(KNN_BLOCK)
+k_knn_chunk(const float* __restrict__ points, int64_t point_stride, const int32_t* __restrict__ n_points, const float* __restrict__ queries,
+            int64_t query_stride, const int32_t* __restrict__ n_queries, int max_queries, int n_chunks, float* __restrict__ ws_d2,
+            int32_t* __restrict__ ws_idx) {
+    __shared__ float tile[KNN_TILE * 3];
+    const int b = blockIdx.y, ch = blockIdx.z;
+    const int nq = n_queries[b], np = n_points[b];
+    if ((int)(blockIdx.x * KNN_BLOCK) >= nq) return;
+    const int per = ((np + n_chunks - 1) / n_chunks + KNN_TILE - 1) / KNN_TILE * KNN_TILE;       // whole tiles per chunk
+    const int p0 = ch * per, p1 = min(np, p0 + per);
+    const int q = blockIdx.x * KNN_BLOCK + threadIdx.x;
+    const bool active = q < nq;
+    const float* P = points + (size_t)b * point_stride;
+    float qx = 0, qy = 0, qz = 0;
+    if (active) {
+        const float* Q = queries + (size_t)b * query_stride + (size_t)q * 3;
+        qx = Q[0];
+        qy = Q[1];
+        qz = Q[2];
+    }
+    float bd[K];
+    int bi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        bd[j] = INFINITY;
+        bi[j] = -1;
+    }
+    for (int t0 = p0; t0 < p1; t0 += KNN_TILE) {
+        const int cnt = min(KNN_TILE, p1 - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt * 3; i += KNN_BLOCK) tile[i] = P[(size_t)t0 * 3 + i];
+        __syncthreads();
+        if (active) {
+            for (int i = 0; i < cnt; ++i) {
+                const float dx = qx - tile[i * 3], dy = qy - tile[i * 3 + 1], dz = qz - tile[i * 3 + 2];
+                const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                const float s = xx + yy;
+                const float d = s + zz;
+                if (d < bd[K - 1]) {
+                    bd[K - 1] = d;
+                    bi[K - 1] = t0 + i;
+#pragma unroll
+                    for (int j = K - 1; j > 0; --j) {
+                        if (bd[j] < bd[j - 1]) {
+                            const float td = bd[j];
+                            bd[j] = bd[j - 1];
+                            bd[j - 1] = td;
+                            const int ti = bi[j];
+                            bi[j] = bi[j - 1];
+                            bi[j - 1] = ti;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (active) {
+        const size_t o = (((size_t)b * max_queries + q) * n_chunks + ch) * K;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            ws_d2[o + j] = bd[j];
+            ws_idx[o + j] = bi[j];
+        }
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(KNN_BLOCK)
+k_knn_merge(const float* __restrict__ ws_d2, const int32_t* __restrict__ ws_idx, const int32_t* __restrict__ n_queries, const int32_t* __restrict__ kk,
+            int max_queries, int n_chunks, float* __restrict__ d2_out, int32_t* __restrict__ idx_out) {
+    const int b = blockIdx.y, q = blockIdx.x * KNN_BLOCK + threadIdx.x;
+    if (q >= n_queries[b]) return;
+    const int k = kk[b];
+    float bd[K];
+    int bi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        bd[j] = INFINITY;
+        bi[j] = -1;
+    }
+    const size_t base = ((size_t)b * max_queries + q) * n_chunks * K;
+    for (int c = 0; c < n_chunks * K; ++c) {              // chunk-major, each chunk's list ascending: ties keep the lower chunk = lower index
+        const float d = ws_d2[base + c];
+        if (d < bd[K - 1]) {
+            bd[K - 1] = d;
+            bi[K - 1] = ws_idx[base + c];
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) {
+                if (bd[j] < bd[j - 1]) {
+                    const float td = bd[j];
+                    bd[j] = bd[j - 1];
+                    bd[j - 1] = td;
+                    const int ti = bi[j];
+                    bi[j] = bi[j - 1];
+                    bi[j - 1] = ti;
+                }
+            }
+        }
+    }
+    const size_t o = ((size_t)b * max_queries + q) * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        if (j < k) {
+            d2_out[o + j] = bd[j];
+            idx_out[o + j] = bi[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // a21 radius-limited KNN (the novel-view renderer, PRE-FF:540-566: neighbours at >= 1 m are discarded right behind the query, so only
 // neighbours INSIDE the radius have to be exact).  Same thread-per-query top-k as k_knn, but a workgroup first boxes its 256 queries
 // (consecutive depth samples of one ray: a thin 5 m segment) and, tile by tile, compacts the points that lie inside the box grown by the
@@ -1012,6 +1129,35 @@ int32_t d3d_knn(const float* points, int64_t point_stride, const int32_t* n_poin
             return D3D_EINVAL;
     }
 #undef D3D_KNN_CASE
+    D3D_LAUNCH_CHECK();
+}
+
+int32_t d3d_knn_chunked(const float* points, int64_t point_stride, const int32_t* n_points, const float* queries, int64_t query_stride,
+                        const int32_t* n_queries, const int32_t* k, int32_t n_batch, int32_t max_queries, int32_t k_max, int32_t n_chunks,
+                        float* ws_d2, int32_t* ws_idx, float* d2, int32_t* idx, void* stream) {
+    if (n_batch <= 0 || max_queries <= 0) return D3D_OK;
+    if (n_chunks < 1 || n_chunks > 4096 || !ws_d2 || !ws_idx) {
+        d3d_set_error_("d3d_knn_chunked: 1 <= n_chunks <= 4096 and workspaces of n_batch * max_queries * n_chunks * k_max elements");
+        return D3D_EINVAL;
+    }
+    dim3 grid((max_queries + KNN_BLOCK - 1) / KNN_BLOCK, n_batch, n_chunks), grid_m((max_queries + KNN_BLOCK - 1) / KNN_BLOCK, n_batch);
+#define D3D_KNNC_CASE(KK)                                                                                                              \
+    case KK:                                                                                                                          \
+        hipLaunchKernelGGL(k_knn_chunk<KK>, grid, dim3(KNN_BLOCK), 0, (hipStream_t)stream, points, point_stride, n_points, queries,    \
+                           query_stride, n_queries, max_queries, n_chunks, ws_d2, ws_idx);                                             \
+        hipLaunchKernelGGL(k_knn_merge<KK>, grid_m, dim3(KNN_BLOCK), 0, (hipStream_t)stream, ws_d2, ws_idx, n_queries, k, max_queries, \
+                           n_chunks, d2, idx);                                                                                         \
+        break;
+    switch (k_max) {
+        D3D_KNNC_CASE(1)
+        D3D_KNNC_CASE(2)
+        D3D_KNNC_CASE(4)
+        D3D_KNNC_CASE(8)
+        default:
+            d3d_set_error_("d3d_knn_chunked: k_max must be 1, 2, 4 or 8");
+            return D3D_EINVAL;
+    }
+#undef D3D_KNNC_CASE
     D3D_LAUNCH_CHECK();
 }
 

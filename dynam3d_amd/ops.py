@@ -237,6 +237,17 @@ class HipOps(FFDevOps):
             self._ck(self.lib.d3d_knn_radius(_ptr(points), point_stride, _ptr(n_points), _ptr(queries), query_stride, _ptr(n_queries), _ptr(k),
                                              n_batch, max_queries, k_max, float(radius), _ptr(d2), _ptr(idx), self._stream()))
             return d2, idx
+        cap = point_stride // 3                                     # capacity of one environment's point set
+        n_wg = n_batch * ((max_queries + 255) // 256)
+        if cap >= 16384 and n_wg < 512:
+            # a large point set under few queries (the Pretrain GT cloud: 4 608 queries x 2e5 points): cut the points into chunks so that the
+            # launch fills the chip (d3d_knn_chunked: bit-identical results)
+            n_chunks = int(min(256, max(2, min(cap // 2048, 1024 // max(n_wg, 1)))))
+            ws_d2 = torch.empty((n_batch, max_queries, n_chunks, k_max), dtype=torch.float32, device=dev)
+            ws_idx = torch.empty((n_batch, max_queries, n_chunks, k_max), dtype=torch.int32, device=dev)
+            self._ck(self.lib.d3d_knn_chunked(_ptr(points), point_stride, _ptr(n_points), _ptr(queries), query_stride, _ptr(n_queries), _ptr(k),
+                                              n_batch, max_queries, k_max, n_chunks, _ptr(ws_d2), _ptr(ws_idx), _ptr(d2), _ptr(idx), self._stream()))
+            return d2, idx
         self._ck(self.lib.d3d_knn(_ptr(points), point_stride, _ptr(n_points), _ptr(queries), query_stride, _ptr(n_queries), _ptr(k),
                                   n_batch, max_queries, k_max, _ptr(d2), _ptr(idx), self._stream()))
         return d2, idx

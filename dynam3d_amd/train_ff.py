@@ -42,16 +42,23 @@ def _stream():
     return _lib.current_stream_ptr()
 
 
+TRAIN_GEMM_SPLIT = __import__("os").environ.get("D3D_TRAIN_GEMM_SPLIT", "1") != "0"
+
+
 def gemm_nt_f32(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """a (M, K) @ w (N, K)^T -> (M, N) float32 on d3d_gemm_nt_f32 (K zero-padded to 16, N to 4: transient copies, nothing cached --
-    the operands of a training step change every step)."""
-    from . import f32_ops  # noqa: F401  (registers the signature)
+    """a (M, K) @ w (N, K)^T -> (M, N) float32 (K / N zero-padded: transient copies, nothing cached -- the operands of a training step
+    change every step).  Default: the split-precision kernel d3d_gemm_nt_f32x3 (fp16 hi + lo, three MFMAs, float32 accumulation: float32
+    accuracy at 16-bit matrix rate) with BOTH operands row-scaled by d3d_row_exponents -- gradients are routinely 1e-6 .. 1e-9, far below
+    fp16's normal range, and the power-of-two row scale makes the split exact for them too.  D3D_TRAIN_GEMM_SPLIT=0: d3d_gemm_nt_f32
+    (v_mfma_f32_16x16x4_f32), the kernel of rounds 3-4."""
+    from . import f32_ops  # noqa: F401  (registers the signatures)
     lib = _lib.load()
     M, K = a.shape
     N = w.shape[0]
     if M == 0 or N == 0:
         return torch.zeros((M, N), dtype=torch.float32, device=a.device)
-    Kp, Np = (K + 15) // 16 * 16, (N + 3) // 4 * 4
+    kq = 32 if TRAIN_GEMM_SPLIT else 16
+    Kp, Np = (K + kq - 1) // kq * kq, (N + 3) // 4 * 4
     if Kp != K or a.stride(1) != 1 or a.stride(0) % 4:
         ap = torch.zeros((M, Kp), dtype=torch.float32, device=a.device)
         ap[:, :K] = a
@@ -61,7 +68,14 @@ def gemm_nt_f32(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         wp[:N, :K] = w
         w = wp
     y = torch.empty((M, Np), dtype=torch.float32, device=a.device)
-    _lib.check(lib.d3d_gemm_nt_f32(_p(a), _p(w), _p(y), None, None, M, Np, Kp, a.stride(0), Kp, Np, 0, _stream()))
+    if TRAIN_GEMM_SPLIT:
+        ea = torch.empty((M,), dtype=torch.int32, device=a.device)
+        ew = torch.empty((Np,), dtype=torch.int32, device=a.device)
+        _lib.check(lib.d3d_row_exponents(_p(a), M, Kp, a.stride(0), _p(ea), None, _stream()))
+        _lib.check(lib.d3d_row_exponents(_p(w), Np, Kp, Kp, _p(ew), None, _stream()))
+        _lib.check(lib.d3d_gemm_nt_f32x3(_p(a), _p(w), _p(y), None, None, M, Np, Kp, a.stride(0), Kp, Np, 0, _p(ea), _p(ew), None, _stream()))
+    else:
+        _lib.check(lib.d3d_gemm_nt_f32(_p(a), _p(w), _p(y), None, None, M, Np, Kp, a.stride(0), Kp, Np, 0, _stream()))
     return y[:, :N]
 
 
@@ -354,17 +368,34 @@ def render_target_from_grid(grid: torch.Tensor, hw: int = 24) -> torch.Tensor:
     return F.avg_pool2d(g, kernel_size=2, stride=2).permute(0, 2, 3, 1).reshape(B, -1, D)
 
 
-def pretrain_step(ff, trainer: FFTrainer, optimizer, update_kwargs: dict, clip_value: float = 10.0, render: Optional[dict] = None) -> dict:
+def pretrain_step(ff, trainer: FFTrainer, optimizer, update_kwargs: dict, clip_value: float = 10.0, render: Optional[dict] = None,
+                  timing: Optional[dict] = None) -> dict:
     """One optimisation step (PRE-TR:479-526) on `ff` (a `Feature_Fields(variant="pretrain")`): forward with loss collection, NaN vote over
     the ranks, backward, gradient all-reduce (average), NaN scrub, value clipping, optimizer step; the updated weights are copied into the
     inference-path modules of `ff`.  `render` = dict(model=train_render.TrainableRenderer, views=[(positions, headings, target (B, 144, 768)),
     ...]): novel views rendered differentiably from the memory this step just updated and aligned with the CLIP patch features of their own
     images (PRE-TR:880-892, 1056-1075); the renderer's parameters must be in `optimizer` too.
+    `timing`: a dict that receives synchronised wall milliseconds per phase (a measurement aid: it serialises host and device).
     Returns {'loss', 'sim_loss', 'segm_loss', 'render_loss', 'skipped', 'collectives'}."""
+    import time as _time
+
+    def lap(name, _t=[None]):
+        if timing is None:
+            return
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        now = _time.perf_counter()
+        if _t[0] is not None and name:
+            timing[name] = timing.get(name, 0.0) + (now - _t[0]) * 1e3
+        _t[0] = now
+
+    lap("")
     optimizer.zero_grad(set_to_none=True)
     trainer.begin()
     ff.update_feature_fields(is_training=True, trainer=trainer, **update_kwargs)
+    lap("update_forward")
     sim, segm = trainer.losses()
+    lap("losses")
     loss = sim if segm is None else sim + segm
     rl = None
     if render is not None:
@@ -380,6 +411,7 @@ def pretrain_step(ff, trainer: FFTrainer, optimizer, update_kwargs: dict, clip_v
         out["skipped"] = True
         return out
     loss.backward()
+    lap("backward")
     params = list(trainer.model.parameters()) + (list(render["model"].parameters()) if render is not None else [])
     zero = lambda p: torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()
     trainer.local_grads = {k: zero(p) for k, p in zip(trainer.model.names, trainer.model.plist)}      # this rank's own, raw (kept for the tests)
@@ -389,8 +421,11 @@ def pretrain_step(ff, trainer: FFTrainer, optimizer, update_kwargs: dict, clip_v
     out["collectives"] = DD.all_reduce_gradients(params, average=True, nan_to_zero=True)
     torch.nn.utils.clip_grad_value_(params, clip_value)                # PRE-TR:517
     trainer.last_grads = {k: zero(p) for k, p in zip(trainer.model.names, trainer.model.plist)}
+    lap("allreduce_scrub_clip")
     optimizer.step()
+    lap("optimizer")
     sync_weights(ff, trainer.model)
+    lap("sync_weights")
     if render is not None:
         sync_render_weights(ff, render["model"])
     return out

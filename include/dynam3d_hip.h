@@ -162,6 +162,13 @@ int32_t d3d_frustum_mask(const float* points_d, int64_t n, const float* depth_d,
 int32_t d3d_knn(const float* points_d, int64_t point_stride, const int32_t* n_points_d, const float* queries_d,
                 int64_t query_stride, const int32_t* n_queries_d, const int32_t* k_d, int32_t n_batch,
                 int32_t max_queries, int32_t k_max, float* d2_d, int32_t* idx_d, void* stream);
+/* d3d_knn for LARGE point sets (the Pretrain GT instance cloud, PRE-FF:977-983): the point range is cut into n_chunks pieces that run as
+ * separate workgroups (d3d_knn gives one workgroup ALL points of its environment: 24 workgroups for 4 608 queries x 2e5 points), partial
+ * top-k lists in the caller's workspaces ws_d2_d / ws_idx_d (n_batch * max_queries * n_chunks * k_max elements each), merged in ascending
+ * chunk order: the result is bit-identical to d3d_knn (same d^2, ties to the lower index). */
+int32_t d3d_knn_chunked(const float* points_d, int64_t point_stride, const int32_t* n_points_d, const float* queries_d, int64_t query_stride,
+                        const int32_t* n_queries_d, const int32_t* k_d, int32_t n_batch, int32_t max_queries, int32_t k_max, int32_t n_chunks,
+                        float* ws_d2_d, int32_t* ws_idx_d, float* d2_d, int32_t* idx_d, void* stream);
 /* a21  the renderer's query (PRE-FF:540-566: `patch_tree.query(sample_points, 4)` followed by "distance >= 1 m -> index -1, distance 1"):
  * same arguments and layout as d3d_knn, but only neighbours INSIDE `radius` are guaranteed -- every slot whose d^2 < radius^2 holds
  * exactly what d3d_knn reports there (same d^2 bits, same index, same order); a slot beyond the radius holds a farther point or

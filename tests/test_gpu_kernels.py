@@ -275,3 +275,29 @@ def test_kdtree_api_shim_matches_golden(ops):
         d2, idx = tree.query(torch.from_numpy(g[f"q_{i}"]).cuda(), nr_nns_searches=int(g[f"k_{i}"]))
         assert idx.dtype == torch.int64 and np.array_equal(idx.cpu().numpy(), g[f"idx_{i}"])
         assert np.array_equal(bits(d2.cpu().numpy()), bits(g[f"d2_{i}"]))
+
+
+def test_knn_chunked_is_bit_identical_to_knn_on_a_large_cloud():
+    """d3d_knn_chunked (the point range cut across workgroups + ordered merge; taken by ops.knn for the Pretrain GT cloud) against d3d_knn:
+    same d^2 bits, same indices, ties to the lower index -- incl. exact duplicates placed in different chunks."""
+    import ctypes as C
+    from dynam3d_amd.ops import HipOps, _ptr
+    ops = HipOps()
+    torch.manual_seed(0)
+    B, N, Q = 3, 50000, 700
+    pts = torch.rand(B, N, 3, device="cuda") * 10 - 5
+    pts[:, 40000] = pts[:, 7]                                   # duplicates far apart in index: a tie across chunks
+    pts[:, 49999] = pts[:, 123]
+    q = torch.rand(B, Q, 3, device="cuda") * 10 - 5
+    q[:, 0] = pts[:, 7]
+    q[:, 1] = pts[:, 123]
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device="cuda")
+    n_pts, n_q = i32([N, N - 17, 30000]), i32([Q, Q - 5, 300])
+    for K in (1, 4):
+        kk = i32([K] * B)
+        d_ref = torch.full((B, Q, K), float("inf"), device="cuda")
+        i_ref = torch.full((B, Q, K), -1, dtype=torch.int32, device="cuda")
+        ops._ck(ops.lib.d3d_knn(_ptr(pts), N * 3, _ptr(n_pts), _ptr(q), Q * 3, _ptr(n_q), _ptr(kk), B, Q, K, _ptr(d_ref), _ptr(i_ref), ops._stream()))
+        d_c, i_c = ops.knn(pts, N * 3, n_pts, q, Q * 3, n_q, kk, B, Q, K)          # cap 50 000 >= 16 384, 9 workgroups: the chunked path
+        assert torch.equal(i_c, i_ref) and torch.equal(d_c.view(torch.int32), d_ref.view(torch.int32))
+        assert int(i_ref[0, 0, 0]) == 7 and int(i_ref[0, 1, 0]) == 123           # the lower index of each duplicate pair

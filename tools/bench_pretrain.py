@@ -5,7 +5,7 @@
 The step = frustum delete + 4-view memory update with loss collection (set encoders forward on the float32 MFMA GEMM, GT labelling by
 d3d_knn over the GT cloud, ground-truth merges) + backward (dx / dW GEMMs, LayerNorm / GELU / set-attention backward kernels) + gradient
 all-reduce (world 1: none) + AdamW + weight sync.  The GEMM share is measured with HIP events around every d3d_gemm_nt_f32 call
-(forward, dx, dW) of the timed steps; its FLOPs are 2 M N K of each call."""
+(forward, dx, dW) of the timed steps; its FLOPs are 2 M N K of each call (algorithmic: the split kernel issues three MFMAs per product)."""
 import argparse
 import json
 import os
@@ -60,7 +60,7 @@ def main():
         return y
 
     TF.gemm_nt_f32 = timed_gemm
-    times, losses = [], []
+    times, losses, phases = [], [], {}
     for t in range(a.warmup + a.steps):
         inp = step_inputs(eps, rng, B, V)
         gemm["on"] = t >= a.warmup
@@ -68,7 +68,8 @@ def main():
         t0 = time.perf_counter()
         ff.delete_old_features_from_camera_frustum(torch.from_numpy(inp["depth_full"]), inp["positions"], inp["headings"], view_ids=vids)
         res = TF.pretrain_step(ff, trainer, opt, dict(batch_depth=inp["depth24"], batch_grid_ft=inp["grid"], batch_position=inp["positions"],
-                                                      batch_heading=inp["headings"], patch_segm=inp["patch_segm"], view_ids=vids, batch_image_ft=inp["img"]))
+                                                      batch_heading=inp["headings"], patch_segm=inp["patch_segm"], view_ids=vids, batch_image_ft=inp["img"]),
+                               timing=phases if (os.environ.get("BENCH_PRETRAIN_PHASES") == "1" and t >= a.warmup) else None)
         torch.cuda.synchronize()
         if t >= a.warmup:
             times.append((time.perf_counter() - t0) * 1e3)
@@ -84,7 +85,8 @@ def main():
                                                            "gemm_gflop_per_step": round(gemm["flop"] / a.steps / 1e9, 1),
                                                            "gemm_tflops_fp32": round(gemm["flop"] / (gemm["ms"] * 1e-3) / 1e12, 1),
                                                            "fp32_mfma_peak_tflops": 157.3, "gemm_frac_of_fp32_mfma_peak": round(gemm["flop"] / (gemm["ms"] * 1e-3) / 157.3e12, 3),
-                                                           "kernel": "d3d_gemm_nt_f32 (v_mfma_f32_16x16x4_f32): forward, dx and dW of every Linear"},
+                                                           "kernel": "d3d_gemm_nt_f32x3 (row-scaled fp16 hi + lo split, three MFMAs) incl. its two d3d_row_exponents launches; D3D_TRAIN_GEMM_SPLIT=0: d3d_gemm_nt_f32 -- forward, dx and dW of every Linear"},
+                          phases_ms_per_step=({k: round(v / a.steps, 2) for k, v in phases.items()} if phases else "BENCH_PRETRAIN_PHASES=1 (synchronising) to measure"),
                           loss_first_last=[round(losses[0], 4), round(losses[-1], 4)], collectives_per_step=res["collectives"])))
 
 
