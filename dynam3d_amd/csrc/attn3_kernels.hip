@@ -33,7 +33,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using float16v = __attribute__((ext_vector_type(16))) float;
 using v4s = __attribute__((ext_vector_type(4))) short;
 
-constexpr int BKV = 64, NW = 4, NT = NW * 64, BQ = NW * 32;
+constexpr int BKV = 64, NW4 = 4, BQ4 = NW4 * 32;     // (NW: a template parameter of the kernel; 4 waves = 128 query rows is the default)
 
 template <bool BF16>
 __device__ __forceinline__ float16v mfma32(const uint4& a, const uint4& b, float16v c) {
@@ -107,11 +107,13 @@ __device__ __forceinline__ void dma_piece(uint32_t voff, const void* base, uint3
         : "memory");
 }
 
-template <bool BF16, int HD, bool CAUSAL>
-__global__ void __launch_bounds__(NT, 2)
+// NW = waves per workgroup (32 query rows each).  4 everywhere except the ViT shape (non-causal, 577 rows, head_dim 64), where 5 waves = 160
+// rows make ceil(577 / 160) x 16 heads x 8 images = 512 workgroups = ONE round of the chip's 512 slots instead of 640 = two (round 5).
+template <bool BF16, int HD, bool CAUSAL, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, NW == 5 ? 3 : 2)     // (second argument = waves per SIMD: two 5-wave workgroups per CU need 3)
 k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int S, int H, int64_t row_stride, int64_t batch_stride, int q_off, int k_off,
                  int v_off, float scale_log2e, int seq_len, const int32_t* __restrict__ cu, int n_qblocks, int window, int nx, int B,
-                 const float* __restrict__ rope_cos, const float* __restrict__ rope_sin) {
+                 const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int32_t* __restrict__ wg_table) {
     constexpr int KS = HD / 16;              // 16-deep MFMA steps over head_dim (QK^T)
     constexpr int DB = HD / 32;              // 32-wide head-dim blocks (PV)
     constexpr int CH = HD / 8;               // 16-byte chunks per row
@@ -119,9 +121,11 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
     constexpr int KST = KSLOT * 8;           // K row stride (elements): 256 B / 128 B
     constexpr int VST = 96, VSLOT = 12;      // V row stride 192 B = 12 slots (see attn2_kernels.hip: the transposing read's bank spread)
     constexpr int KBUF = BKV * KST, VBUF = BKV * VST;
-    constexpr int KPW = BKV * KST * 2 / 1024 / NW;       // K pieces per wave and tile: 4 (hd 96) / 2 (hd 64)
-    constexpr int VPW = BKV * VST * 2 / 1024 / NW;       // V pieces per wave and tile: 3
-    static_assert(KPW * NW * 1024 == KBUF * 2 && VPW * NW * 1024 == VBUF * 2, "tile = whole pieces");
+    constexpr int BQ = NW * 32;
+    constexpr int KPT = BKV * KST * 2 / 1024, VPT = BKV * VST * 2 / 1024;    // 1 KiB pieces per tile: K 16 (hd 96) / 8 (hd 64), V 12
+    constexpr int KPW = (KPT + NW - 1) / NW;             // K pieces per wave and tile: 4 (hd 96) / 2 (hd 64); piece wave + i * NW exists if < KPT
+    constexpr int VPW = (VPT + NW - 1) / NW;             // V pieces per wave and tile: 3
+    static_assert(KPT * 1024 == KBUF * 2 && VPT * 1024 == VBUF * 2, "tile = whole pieces");
     __shared__ __attribute__((aligned(1024))) uint16_t Ks[2 * KBUF];
     __shared__ __attribute__((aligned(1024))) uint16_t Vs[2 * VBUF];
 
@@ -130,7 +134,21 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
     const int li = lane & 31, hi = lane >> 5;
     // XCD-aware placement (attn2_kernels.hip): the `nx` workgroups of one (sequence, head) are consecutive slots of ONE XCD
     int h, b, xq;
-    {
+    // Scheduled launch (round 5, packed causal prefill): `wg_table[blockIdx.x]` = (sequence << 20 | head << 8 | query block) -- ONE query
+    // block per workgroup, heaviest blocks first (the host orders them; the dispatcher hands workgroups out in index order as slots free
+    // up, so the ragged tail of a causal batch fills with small blocks instead of waiting for paired ones: 896 paired workgroups of 14-16
+    // tiles on 512 slots were two full rounds; 1 664 single blocks of 2-16 tiles pack to ~26 tile-times), entry p on XCD p % 8 = the XCD of
+    // its (sequence, head).  Every query block is computed exactly as in the paired launch: bit-identical results.  MEASURED SLOWER in the
+    // step (Phi-3 prefill 40.4 -> 41.4 ms, profiles/r05_attention_schedule_ab.txt): the level-by-level order spreads a head's query blocks
+    // over the whole launch, so its keys / values are fetched again from the Infinity Cache instead of the XCD's L2 that the paired,
+    // head-adjacent grid keeps them in -- the callers leave it off (D3D_ATTN_SCHED=1 turns it on in towers.py).
+    const bool tab = wg_table != nullptr;
+    if (tab) {
+        const int e = wg_table[blockIdx.x];
+        b = e >> 20;
+        h = (e >> 8) & 0xfff;
+        xq = e & 0xff;
+    } else {
         const int lin = blockIdx.x, G = H * B, G8 = G & ~7;
         if (lin < G8 * nx) {
             const int xcd = lin & 7, slot = lin >> 3, k = slot / nx;
@@ -160,7 +178,7 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
         n_qblocks = (S + BQ - 1) / BQ;
         base = qkv + row0 * row_stride;
     }
-    if (CAUSAL ? xq >= (n_qblocks + 1) / 2 : xq >= n_qblocks) return;
+    if (tab ? xq >= n_qblocks : (CAUSAL ? xq >= (n_qblocks + 1) / 2 : xq >= n_qblocks)) return;
     const uint16_t* Qp = base + (int64_t)(q_off + h) * HD;
     const uint16_t* Kp = base + (int64_t)(k_off + h) * HD;
     const uint16_t* Vp = base + (int64_t)(v_off + h) * HD;
@@ -201,20 +219,24 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
         const char* kb = reinterpret_cast<const char*>(Kp) + (int64_t)T * tile_bytes;
         const char* vb = reinterpret_cast<const char*>(Vp) + (int64_t)T * tile_bytes;
         const int last = S - 1 - T * BKV;                  // last valid row of the tile (>= 0)
-        if (last >= BKV - 1) {
+        if (NW == 4 && last >= BKV - 1) {                 // (NW 5 recomputes its offsets every tile -- a handful of VALU operations -- instead of
+#pragma unroll                                            //  holding five more registers: it has to fit 168 for three waves per SIMD)
+            for (int i = 0; i < KPW; ++i)
+                if (KPT % NW == 0 || wave + i * NW < KPT) dma_piece(koff[i], kb, lds_k + (uint32_t)(buf * KBUF * 2 + (wave + i * NW) * 1024));
 #pragma unroll
-            for (int i = 0; i < KPW; ++i) dma_piece(koff[i], kb, lds_k + (uint32_t)(buf * KBUF * 2 + (wave + i * NW) * 1024));
-#pragma unroll
-            for (int i = 0; i < VPW; ++i) dma_piece(voff[i], vb, lds_v + (uint32_t)(buf * VBUF * 2 + (wave + i * NW) * 1024));
+            for (int i = 0; i < VPW; ++i)
+                if (VPT % NW == 0 || wave + i * NW < VPT) dma_piece(voff[i], vb, lds_v + (uint32_t)(buf * VBUF * 2 + (wave + i * NW) * 1024));
         } else {
 #pragma unroll
             for (int i = 0; i < KPW; ++i) {
+                if (!(KPT % NW == 0 || wave + i * NW < KPT)) continue;
                 int r, c;
                 k_src(i, r, c);
                 dma_piece((uint32_t)(((int64_t)min(r, last) * row_stride + c * 8) * 2), kb, lds_k + (uint32_t)(buf * KBUF * 2 + (wave + i * NW) * 1024));
             }
 #pragma unroll
             for (int i = 0; i < VPW; ++i) {
+                if (!(VPT % NW == 0 || wave + i * NW < VPT)) continue;
                 int r, c;
                 v_src(i, r, c);
                 dma_piece((uint32_t)(((int64_t)min(r, last) * row_stride + c * 8) * 2), vb, lds_v + (uint32_t)(buf * VBUF * 2 + (wave + i * NW) * 1024));
@@ -228,8 +250,9 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
     const int v_off0 = (hi * 4 + ((lane & 15) >> 2)) * VST + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
 
   for (int pass = 0; pass < (CAUSAL ? 2 : 1); ++pass) {
-    const int qb = CAUSAL ? (pass == 0 ? n_qblocks - 1 - xq : xq) : xq;
-    if (CAUSAL && pass == 1 && qb == n_qblocks - 1 - xq) break;          // odd count: the middle block stands alone
+    if (tab && pass == 1) break;                                         // scheduled launch: one query block per workgroup
+    const int qb = (CAUSAL && !tab) ? (pass == 0 ? n_qblocks - 1 - xq : xq) : xq;
+    if (CAUSAL && !tab && pass == 1 && qb == n_qblocks - 1 - xq) break;  // odd count: the middle block stands alone
     const int q0 = qb * BQ, qw = q0 + wave * 32;
     const int qrow = qw + li;                                            // this lane's query
 
@@ -452,6 +475,11 @@ int32_t d3d_flash_attention_v3_rope_q(const void* qkv, void* out, int32_t B, int
                                       int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len, const int32_t* cu_seqlens,
                                       int32_t window, const float* rope_cos, const float* rope_sin, int32_t dtype, void* stream);
 
+int32_t d3d_flash_attention_v3_sched(const void* qkv, void* out, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride, int64_t batch_stride,
+                                     int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len, const int32_t* cu_seqlens,
+                                     int32_t window, const float* rope_cos, const float* rope_sin, const int32_t* wg_table, int32_t n_wg, int32_t dtype,
+                                     void* stream);
+
 // Same contract as d3d_flash_attention_v2 (attn2_kernels.hip); 128 query rows per workgroup.
 int32_t d3d_flash_attention_v3(const void* qkv, void* out, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride, int64_t batch_stride,
                                int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len, const int32_t* cu_seqlens, int32_t window,
@@ -463,7 +491,19 @@ int32_t d3d_flash_attention_v3(const void* qkv, void* out, int32_t B, int32_t S,
 int32_t d3d_flash_attention_v3_rope_q(const void* qkv, void* out, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride, int64_t batch_stride,
                                       int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len, const int32_t* cu_seqlens,
                                       int32_t window, const float* rope_cos, const float* rope_sin, int32_t dtype, void* stream) {
+    return d3d_flash_attention_v3_sched(qkv, out, B, S, H, head_dim, row_stride, batch_stride, q_off, k_off, v_off, causal, seq_len, cu_seqlens, window,
+                                        rope_cos, rope_sin, nullptr, 0, dtype, stream);
+}
+
+int32_t d3d_flash_attention_v3_sched(const void* qkv, void* out, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride, int64_t batch_stride,
+                                     int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len, const int32_t* cu_seqlens,
+                                     int32_t window, const float* rope_cos, const float* rope_sin, const int32_t* wg_table, int32_t n_wg, int32_t dtype,
+                                     void* stream) {
     if (B <= 0 || S <= 0) return D3D_OK;
+    if (wg_table && (n_wg <= 0 || H > 4095 || B > 2047)) {
+        d3d_set_error_("d3d_flash_attention_v3_sched: a workgroup table needs n_wg > 0, H <= 4095, B <= 2047");
+        return D3D_EINVAL;
+    }
     if ((head_dim != 64 && head_dim != 96) || (row_stride & 7) || (batch_stride & 7) || window < 0 || (window > 0 && !causal)) {
         d3d_set_error_("d3d_flash_attention_v3: head_dim must be 64 or 96; strides multiples of 8 elements; a window needs causal");
         return D3D_EINVAL;
@@ -480,12 +520,38 @@ int32_t d3d_flash_attention_v3_rope_q(const void* qkv, void* out, int32_t B, int
     hipStream_t s = (hipStream_t)stream;
     const uint16_t* q = (const uint16_t*)qkv;
     uint16_t* o = (uint16_t*)out;
-    const int nqb = (S + BQ - 1) / BQ;
+    // 5-wave workgroups (160 query rows) when that saves a round of the chip's slots (two workgroups per CU): dense non-causal head_dim 64
+    // -- the ViT shape: 577 rows x 16 heads x 8 images = 640 workgroups of 128 rows on 512 slots, 512 of 160 rows.  MEASURED SLOWER
+    // (profiles/r05_attention_schedule_ab.txt: each ViT tower 4.97 -> 5.14 ms; ten waves per CU at three per SIMD contend for the VALU
+    // that bounds this kernel): OFF unless D3D_ATTN_NW5=1; bit-identical results, kept as a tested knob.
+    bool nw5 = false;
+    if (!causal && head_dim == 64 && !cu_seqlens && !wg_table) {
+        const char* e5 = getenv("D3D_ATTN_NW5");                     // (read per call: the test compares the two launches in one process)
+        const bool allow = e5 && e5[0] == '1';
+        static const int slots = [] {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            return 2 * cus;
+        }();
+        const int64_t n4 = (int64_t)((S + 127) / 128) * H * B, n5 = (int64_t)((S + 159) / 160) * H * B;
+        nw5 = allow && (n5 + slots - 1) / slots < (n4 + slots - 1) / slots;
+    }
+    const int bq = nw5 ? 160 : BQ4;
+    const int nqb = (S + bq - 1) / bq;
     if (window >= S) window = 0;
     const int nx = causal ? (nqb + 1) / 2 : nqb;
-    dim3 grid((unsigned)((int64_t)nx * H * B)), block(NT);
+    dim3 grid(wg_table ? (unsigned)n_wg : (unsigned)((int64_t)nx * H * B)), block(nw5 ? 320 : NW4 * 64);
+    if (nw5) {
+        if (dtype == 0)
+            hipLaunchKernelGGL((k_flash_attn_dma<true, 64, false, 5>), grid, block, 0, s, q, o, S, H, row_stride, batch_stride, q_off, k_off, v_off, sl2, seq_len,
+                               cu_seqlens, nqb, window, nx, B, rope_cos, rope_sin, wg_table);
+        else
+            hipLaunchKernelGGL((k_flash_attn_dma<false, 64, false, 5>), grid, block, 0, s, q, o, S, H, row_stride, batch_stride, q_off, k_off, v_off, sl2, seq_len,
+                               cu_seqlens, nqb, window, nx, B, rope_cos, rope_sin, wg_table);
+        D3D_LAUNCH_CHECK();
+    }
 #define D3D_FA3(BF, HDV, CA) hipLaunchKernelGGL((k_flash_attn_dma<BF, HDV, CA>), grid, block, 0, s, q, o, S, H, row_stride, batch_stride, q_off, k_off, v_off, \
-                                                sl2, seq_len, cu_seqlens, nqb, window, nx, B, rope_cos, rope_sin)
+                                                sl2, seq_len, cu_seqlens, nqb, window, nx, B, rope_cos, rope_sin, wg_table)
     if (dtype == 0) {
         if (head_dim == 96) { if (causal) D3D_FA3(true, 96, true); else D3D_FA3(true, 96, false); }
         else { if (causal) D3D_FA3(true, 64, true); else D3D_FA3(true, 64, false); }

@@ -201,10 +201,15 @@ def rope_packed_(qkv2d: torch.Tensor, n_rot_heads: int, head_dim: int, cos, sin,
 
 
 def attention_packed(qkv3: torch.Tensor, n_heads: int, causal: bool, cu_seqlens: torch.Tensor, n_seq: int, max_len: int, n_valid=None, window: int = 0,
-                     out=None, rope_q=None):
-    """`rope_q` = (cos, sin): the buffer's queries are NOT rotated yet, the kernel rotates them (see `can_fuse_rope_q`)."""
+                     out=None, rope_q=None, sched=None):
+    """`rope_q` = (cos, sin): the buffer's queries are NOT rotated yet, the kernel rotates them (see `can_fuse_rope_q`).
+    `sched`: workgroup table from `attention_schedule` (one query block per workgroup, heaviest first)."""
     _hit("attention")
-    return _hip.attention_packed(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid, window, out, rope_q)
+    return _hip.attention_packed(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid, window, out, rope_q, sched)
+
+
+def attention_schedule(lens, n_heads: int, device) -> torch.Tensor:
+    return torch.from_numpy(_hip.attention_schedule(lens, n_heads)).to(device)
 
 
 def can_fuse_rope_q() -> bool:

@@ -21,6 +21,7 @@ _lib.register("d3d_rope_inplace", [vp, vp, vp, i32, i32, i32, i32, i64, vp, i32,
 _lib.register("d3d_set_attention", [vp, vp, i32, i32, i32, i32, vp, vp])
 _lib.register("d3d_flash_attention_v3", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, i32, vp])
 _lib.register("d3d_flash_attention_v3_rope_q", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp])
+_lib.register("d3d_flash_attention_v3_sched", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, vp])
 _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
 _lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
 _lib.register("d3d_decode_attention", [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp])
@@ -239,7 +240,32 @@ class HipDense:
         """The attention kernel can rotate the queries itself (d3d_flash_attention_v3_rope_q)."""
         return True
 
-    def attention_packed(self, qkv, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid=None, window=0, out=None, rope_q=None):
+    @staticmethod
+    def attention_schedule(lens, n_heads, block=128):
+        """Workgroup table of `d3d_flash_attention_v3_sched` for a packed causal batch: one entry (sequence << 20 | head << 8 | query block)
+        per (sequence, head, query block), heaviest first -- query block q of a sequence attends to 2 (q + 1) key tiles, so the table goes
+        level by level from the highest block index down --, and inside a level the (sequence, head) pairs are dealt to positions whose
+        index mod 8 is the pair's XCD (sequence * H + head) % 8 (an XCD's L2 then serves all query blocks of a head).  numpy int32."""
+        import numpy as np
+        nqb = [(int(n) + block - 1) // block for n in lens]
+        out = []
+        for q in range(max(nqb) - 1, -1, -1):
+            buckets = [[] for _ in range(8)]
+            for b, n in enumerate(nqb):
+                if q < n:
+                    for h in range(n_heads):
+                        buckets[(b * n_heads + h) % 8].append((b << 20) | (h << 8) | q)
+            # positions advance through the whole table: entry p of this level sits at len(out) + p; deal so that (len(out) + p) % 8 = bucket
+            depth = max(len(x) for x in buckets)
+            start = len(out) % 8
+            for r in range(depth):
+                for k in range(8):
+                    bk = buckets[(start + k) % 8]
+                    if r < len(bk):
+                        out.append(bk[r])
+        return np.asarray(out, np.int32)
+
+    def attention_packed(self, qkv, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid=None, window=0, out=None, rope_q=None, sched=None):
         """PACKED variable-length batch: qkv (T, 3H, hd) rows of sequence b = [cu[b], cu[b+1]) -> (T, H, hd).  Rows beyond
         cu[-1] (padding of the packed buffer) come back zero; `n_valid` = cu[-1] as a host int saves zero-filling the rest.
         `out`: a caller-owned (T, H, hd) buffer whose padding rows are already zero (the kernel writes rows < cu[-1] only)."""
@@ -252,6 +278,13 @@ class HipDense:
             out = torch.empty((T, n_heads, hd), dtype=qkv.dtype, device=qkv.device)
             if n_valid < T:
                 out[n_valid:].zero_()
+        if sched is not None:                                     # (int32 device tensor from attention_schedule: causal packed batches)
+            cos, sin = rope_q if rope_q is not None else (None, None)
+            assert causal and sched.dtype == torch.int32 and sched.is_cuda
+            _lib.check(self.lib.d3d_flash_attention_v3_sched(_p(qkv), _p(out), n_seq, max_len, n_heads, hd, Ht * hd, 0, 0, n_heads, 2 * n_heads, 1, max_len,
+                                                             _p(cu_seqlens), window, _p(cos), _p(sin), _p(sched), int(sched.numel()),
+                                                             0 if qkv.dtype == torch.bfloat16 else 1, self._stream()))
+            return out
         if rope_q is not None:
             cos, sin = rope_q                                     # (positions >= max_len, hd / 2) float32, contiguous
             assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()

@@ -354,7 +354,13 @@ class Phi3Decoder:
         attn_out = torch.empty((Tp, self.cfg.heads, self.cfg.head_dim), dtype=self.dtype, device=self.device)
         if cu_h[-1] < Tp:
             attn_out[cu_h[-1]:].zero_()
-        return dict(cu=cu, cu_h=cu_h, pos=pos, cos=cos, sin=sin, max_len=max_len, last_rows=(cu[1:] - 1).long(), B=len(lens), Tp=Tp, attn_out=attn_out)
+        # D3D_ATTN_SCHED=1: one query block per attention workgroup, heaviest first (hip_dense.attention_schedule; bit-identical results).
+        # Off by default: measured 1 ms SLOWER per step than the paired, head-adjacent launch (profiles/r05_attention_schedule_ab.txt)
+        sched = D.attention_schedule(lens, self.cfg.heads, self.device) if self.ATTN_SCHED else None
+        return dict(cu=cu, cu_h=cu_h, pos=pos, cos=cos, sin=sin, max_len=max_len, last_rows=(cu[1:] - 1).long(), B=len(lens), Tp=Tp, attn_out=attn_out,
+                    sched=sched)
+
+    ATTN_SCHED = os.environ.get("D3D_ATTN_SCHED", "0") == "1"
 
     # rotate the queries inside the attention kernel (d3d_flash_attention_v3_rope_q) when the backend can; D3D_FUSE_ROPE_Q=0: in place, with the keys
     FUSE_ROPE_Q = os.environ.get("D3D_FUSE_ROPE_Q", "1") != "0"
@@ -379,7 +385,7 @@ class Phi3Decoder:
             keep_kv.append(qkv)                                        # (only its k / v heads are read afterwards)
         a = D.attention_packed(qkv.view(Tp, Ht, c.head_dim), c.heads, True, ctx["cu"], ctx["B"], ctx["max_len"], n_valid=ctx["cu_h"][-1],
                                window=self.SLIDING_WINDOW if ctx["max_len"] > self.SLIDING_WINDOW else 0, out=ctx.get("attn_out"),
-                               rope_q=(ctx["cos"], ctx["sin"]) if fuse_q else None)
+                               rope_q=(ctx["cos"], ctx["sin"]) if fuse_q else None, sched=ctx.get("sched"))
         a = a.view(Tp, c.heads * c.head_dim)
         if prune:
             a, x = a[ctx["last_rows"]].contiguous(), x[ctx["last_rows"]].contiguous()

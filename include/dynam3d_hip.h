@@ -416,6 +416,15 @@ int32_t d3d_flash_attention_v3_rope_q(const void* qkv_d, void* out_d, int32_t B,
                                       int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
                                       const int32_t* cu_seqlens_d, int32_t window, const float* rope_cos_d, const float* rope_sin_d, int32_t dtype,
                                       void* stream);
+/* The same with a caller-built SCHEDULE (packed causal prefill, ragged prompts): wg_table_d[i] = (sequence << 20) | (head << 8) | query block
+ * (128 queries per block) -- one query block per workgroup, launched in table order; n_wg entries.  The caller lists the heaviest blocks
+ * (highest query block of each sequence) first and puts entry i of a (sequence, head) on i % 8 == (sequence * H + head) % 8 so that one
+ * XCD's L2 serves that head's keys (dynam3d_amd/hip_dense.py attention_schedule).  Results are bit-identical to the unscheduled launch
+ * (which pairs query blocks i and n-1-i per workgroup).  wg_table_d null = d3d_flash_attention_v3_rope_q. */
+int32_t d3d_flash_attention_v3_sched(const void* qkv_d, void* out_d, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride,
+                                     int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,
+                                     const int32_t* cu_seqlens_d, int32_t window, const float* rope_cos_d, const float* rope_sin_d,
+                                     const int32_t* wg_table_d, int32_t n_wg, int32_t dtype, void* stream);
 /* self-attention inside packed variable-length token sets (set encoders VLN-FF:134-155): float32, head_dim 64.
  * qkv (T, 3*H*64) = [q|k|v]; set g = tokens [set_off[g], set_off[g+1]); q_rows > 0 restricts the queries to the
  * first q_rows rows of every set (1 = CLS only).  out (T, H*64); rows that are not queried are left untouched. */

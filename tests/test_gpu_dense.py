@@ -342,6 +342,13 @@ def test_flash_attention_fused_query_rope_equals_separate_rope(hd, dt):
         assert torch.equal(b_[:, H * d:], a[:, H * d:]) and torch.equal(b_[:, :H * d], qkv[:, :H * d])
         out = hd.attention_packed(b_.view(Tp, 3 * H, d), H, True, cu, len(lens), S, n_valid=T, window=window, rope_q=(cos, sin))
         assert torch.equal(out, ref), (H, d, lens, window, float((out.float() - ref.float()).abs().max()))
+        # the SCHEDULED launch (d3d_flash_attention_v3_sched: one query block per workgroup, heaviest first) computes every block exactly
+        # as the paired launch does: same bits, with and without the fused query rotation
+        tab = torch.from_numpy(hd.attention_schedule(lens, H)).cuda()
+        assert tab.numel() == sum((n + 127) // 128 for n in lens) * H
+        o1 = hd.attention_packed(b_.view(Tp, 3 * H, d), H, True, cu, len(lens), S, n_valid=T, window=window, rope_q=(cos, sin), sched=tab)
+        o2 = hd.attention_packed(a.view(Tp, 3 * H, d), H, True, cu, len(lens), S, n_valid=T, window=window, sched=tab)
+        assert torch.equal(o1, ref) and torch.equal(o2, ref), (H, d, lens, window)
 
 
 def test_flash_attention_sliding_window(hd):
@@ -425,3 +432,23 @@ def test_decode_attention_kv_cache(hd, dt, tol, split, monkeypatch):
         ka, kb = kn_a[:, :t + 1].float(), kn_b[:, :t + 1].float()
         ne = ka != kb
         assert float(ne.float().mean()) < 1e-3 and float(((ka - kb).abs() / ka.abs().clamp_min(1e-3))[ne].max() if ne.any() else 0.0) < (1e-2 if dt == torch.bfloat16 else 2e-3)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 1e-3), (torch.bfloat16, 6e-3)])
+def test_vit_shape_attention_five_wave_workgroups(hd, dt, tol, monkeypatch):
+    """The ViT towers' shape -- 8 images x 16 heads x 577 rows, head_dim 64, non-causal -- can be launched with 5-wave workgroups (160 query
+    rows: 512 workgroups = one round of the chip instead of 640 = two; D3D_ATTN_NW5=1 -- measured slower in the step, so a knob).  Same
+    arithmetic per query: bit-identical to the default 4-wave launch, and both against float32 softmax attention."""
+    torch.manual_seed(21)
+    B, S, H, d = 8, 577, 16, 64
+    qkv = (torch.randn(B, S, 3 * H, d, device="cuda") * 0.7).to(dt)
+    out4 = hd.attention_qkv(qkv, H, False)
+    monkeypatch.setenv("D3D_ATTN_NW5", "1")
+    out5 = hd.attention_qkv(qkv, H, False)
+    monkeypatch.delenv("D3D_ATTN_NW5")
+    assert torch.equal(out5, out4)
+    q, k, v = (qkv[:, :, i * H:(i + 1) * H].transpose(1, 2).float() for i in range(3))
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2)
+    assert rel(out5.float(), ref) < tol
+    # a shape where 160-row blocks do not save a round keeps the 4-wave kernel (nothing to compare, just runs): 2 images
+    assert torch.isfinite(hd.attention_qkv(qkv[:2].contiguous(), H, False).float()).all()
