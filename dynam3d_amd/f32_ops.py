@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Dict, Optional
 
 import torch
@@ -100,8 +101,8 @@ class F32Ops:
         """Row exponents of a (padded) weight, cached on the source tensor's storage + version like the padded copy."""
         key, tag = w.data_ptr(), (w._version, tuple(wp.shape))
         hit = self._wexp.get(key)
-        if hit is None or hit[0] != tag:
-            hit = self._wexp[key] = (tag, self.row_exponents(wp))
+        if hit is None or hit[0] != tag or hit[2]() is not w:
+            hit = self._wexp[key] = (tag, self.row_exponents(wp), weakref.ref(w))
         return hit[1]
 
     def prep_weight(self, w: torch.Tensor) -> torch.Tensor:
@@ -111,13 +112,14 @@ class F32Ops:
             return w
         # keyed on the storage AND its version counter: an in-place update (optimizer step, load_state_dict) or a new tensor allocated
         # at a freed address must not be served another tensor's / an older padded copy; one entry per address, so updates replace
+        # ... and on the tensor OBJECT (a weak reference): a new tensor of the same shape allocated at a freed address starts at version 0 too
         key = w.data_ptr()
         tag = (w._version, N, K)
         hit = self._padded.get(key)
-        if hit is None or hit[0] != tag:
+        if hit is None or hit[0] != tag or hit[2]() is not w:
             wp = torch.zeros((N, (K + self.KPAD - 1) // self.KPAD * self.KPAD), dtype=torch.float32, device=w.device)
             wp[:, :K] = w.detach()
-            hit = self._padded[key] = (tag, wp)
+            hit = self._padded[key] = (tag, wp, weakref.ref(w))
         return hit[1]
 
     def linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, act: Optional[str] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:

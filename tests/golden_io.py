@@ -29,6 +29,11 @@ TRAJ_CASES = {
     # patch ids are recycled (VLN-FF:433-475), zone snapshots go stale and zones die and are re-opened (VLN-FF:694-756) for 30 steps
     # on top of each other.  `light`: only the key steps keep the large arrays; every step keeps the id orders, positions, row sums
     # and a hash of the integer bookkeeping.
+    # Degenerate segmentations (the domain's edge cases): step 0 = ONE segment of all 576 patches (what `get_patch_segm` returns when FastSAM
+    # fails, VLN-FF:424-430: the largest possible set, 577 encoder tokens), step 1 = 576 segments of one patch each (the most proposals /
+    # merges / new instances a frame can produce), step 2 = a 1-patch segment beside a 575-patch one, step 3 = the usual 16 blocks, step 4 =
+    # one segment again on top of a populated memory.  B = 1 (a batch of one is an edge case of every per-environment table too).
+    "edge": dict(B=1, steps=5, seed=41, grid_seed=42, stationary=False, wall=None, depth_hw=64, segm_edge=True),
     "long": dict(B=2, steps=32, seed=21, grid_seed=22, stationary=False, wall=2.0, wall_steps=(9, 10, 19, 27), depth_hw=64,
                  light=True, key_steps=(0, 8, 9, 10, 11, 19, 20, 27, 28, 31)),
 }
@@ -87,6 +92,15 @@ def traj_inputs(case):
         dfull = np.stack([G.preprocess_depth(fr.depth)[..., 0] for fr in frs], 1)[idx]                      # (B,V,H,W)
         d24 = np.stack([G.preprocess_depth(G.downsample_depth_nearest(fr.depth)).reshape(B0, 576) for fr in frs], 1)[idx]
         segm = np.stack([fr.patch_segm for fr in frs], 1)[idx]                                              # (B,V,1,24,24)
+        if case.get("segm_edge"):
+            flat = np.zeros((576,), np.int64)
+            if t % 5 == 1:
+                flat = np.arange(576, dtype=np.int64)
+            elif t % 5 == 2:
+                flat[300] = 1                                  # labels stay dense and in `torch.unique` order: {0: 575 patches, 1: one patch}
+            elif t % 5 == 3:
+                flat = segm[0, 0, 0].reshape(-1).copy()
+            segm = np.broadcast_to(flat.reshape(1, 1, 1, 24, 24), segm.shape).copy()
         fr = frs[0]
         yield dict(depth_full=dfull.copy(), depth24=d24.copy(), grid=grid_all[idx].copy(),
                    patch_segm=segm.reshape(len(alive) * V, *segm.shape[2:]).copy(), positions=[fr.positions[i].tolist() for i in alive],
