@@ -72,28 +72,27 @@ THREAD_SWEEP = {}       # threads -> seconds of the probe (printed in the cpu_ba
 
 
 def _best_threads(limit):
-    """torch's fp32 GEMM does not always scale to every core of a large host: take the fastest of a few thread counts up to `limit` on
-    a PREFILL-SHAPED product -- one prompt's rows through one Phi-3 down projection, (821 x 8192) @ (8192 x 3072): the Phi-3 prefill is
-    75 % of the CPU leg, and a square 2048^3 probe (rounds 2-4) picked thread counts that were 2x apart from round to round on the same
-    oracle.  Best of 3 repetitions per count; the smallest count within 15 % of the fastest is taken; the sweep is reported."""
+    """torch's fp32 GEMM does not always scale to every core of a large host: take a thread count from a probe AT THE ORACLE'S OWN SHAPE --
+    the whole right-padded prompt batch through one Phi-3 o_proj, (8 x 821 rows x 3072) @ (3072 x 3072), 124 GFLOP: the Phi-3 prefill is
+    75 % of the CPU leg.  (Rounds 2-4 probed a square 2048^3 product, early round 5 one prompt's rows: both picked counts whose full-step
+    times were 86 s (64 threads) against 105-107 s (96) on the same 128-core box.)  Best of 2 repetitions per count; the SMALLEST count
+    within 10 % of the fastest is taken (the top of the curve is flat); the sweep is reported."""
     best, best_t = min(8, limit), float("inf")
-    a, w = torch.randn(821, 8192), torch.randn(3072, 8192)
-    cand = sorted({n for n in (8, 16, 32, 48, 64, 96, 128, 192, limit) if n <= limit})
+    a, w = torch.randn(8 * 821, 3072), torch.randn(3072, 3072)
+    cand = sorted({n for n in (16, 32, 48, 64, 96, 128, 192, limit) if n <= limit})
     for n in cand:
         torch.set_num_threads(n)
-        torch.nn.functional.linear(a, w)
+        torch.nn.functional.linear(a[:512], w)
         t = float("inf")
-        for _ in range(3):
+        for _ in range(2):
             t0 = time.time()
             torch.nn.functional.linear(a, w)
             t = min(t, time.time() - t0)
         THREAD_SWEEP[n] = round(t, 4)
         if t < best_t:
             best, best_t = n, t
-    # the SMALLEST count within 15 % of the best: the top of the curve is flat (64 / 96 threads differed by 1-12 % from run to run on the
-    # 128-core box while the whole step ran 86 s on 64 and 105 s on 96), and fewer threads leave room for the oracle's own helper threads
     for n in cand:
-        if THREAD_SWEEP[n] <= 1.15 * best_t:
+        if THREAD_SWEEP[n] <= 1.10 * best_t:
             return n
     return best
 
@@ -236,7 +235,7 @@ def cpu_baseline(cfg, seed, B, warm_steps, gpu_lengths=None, gpu_grids=None, gpu
                           else "seeded unit-norm grid features (so merge decisions -- and with them Ni/Nz and S -- differ from the GPU leg's)",
                           sum(orc.last_lengths), sum(gpu_lengths) if gpu_lengths else "n/a")),
                memory_steps_advanced=warm_steps, thread_sweep_seconds=dict(THREAD_SWEEP),
-               thread_probe="one prompt through one down projection: (821 x 8192) @ (8192 x 3072) float32, best of 3",
+               thread_probe="the padded prompt batch through one o_proj: (6568 x 3072) @ (3072 x 3072) float32, best of 2; smallest count within 10 % of the fastest",
                seconds_measured=round(measured, 2), stages=st, seconds_weights=round(t_w, 1), seconds_memory_warmup=round(t_warm, 1))
     if same_state and gpu_logits is not None:
         lowp_logits = None
