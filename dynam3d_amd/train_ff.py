@@ -215,13 +215,19 @@ class FFTrainer:
     def __init__(self, model: TrainableFF, gt_xyz: Optional[Sequence[np.ndarray]] = None, gt_label: Optional[Sequence[np.ndarray]] = None):
         self.model = model
         self.set_gt(gt_xyz, gt_label)
-        self.gt_ids_of_slot: Dict[int, torch.Tensor] = {}          # memory slot -> (m_cap,) GT instance id of every instance row (PRE-FF global_gt_instance_ids)
-        self.begin()
+        self.gt_rows: Optional[torch.Tensor] = None               # (slots, m_cap) int64 ON THE DEVICE: GT instance id of every instance row
+        self.begin()                                               # (PRE-FF global_gt_instance_ids), -1 = none yet
+
+    @property
+    def gt_ids_of_slot(self) -> Dict[int, torch.Tensor]:
+        """memory slot -> (m_cap,) GT ids on the host (a view for tests / inspection; the working copy is `gt_rows`)."""
+        return {} if self.gt_rows is None else {s: self.gt_rows[s].cpu() for s in range(self.gt_rows.shape[0])}
 
     def set_gt(self, gt_xyz, gt_label):
         """Ground-truth point clouds per environment: xyz (Ng, 3) float32 world coordinates, labels (Ng,) int (PRE-FF gt_pcd_tree / gt_pcd_label)."""
         self.gt_xyz, self.gt_label = gt_xyz, gt_label
         self._gt_dev = None
+        self._gt_lab_dev = None
 
     def begin(self):
         self.pred_i, self.tgt_i, self.pred_is, self.tgt_is = [], [], [], []
@@ -264,7 +270,7 @@ class FFTrainer:
         inv[valid_g] = np.arange(len(valid_g))
         self.cur["inv"] = torch.from_numpy(inv).to(dev)
         if self.gt_xyz is not None:
-            self.cur["gt"] = torch.from_numpy(self._label_segments(ops, pools, envs, slots_h, row_base, order, counts, valid_g, n_max)).to(dev)
+            self.cur["gt"] = self._label_segments(ops, pools, envs, slots_h, row_base, order, grp_of_tok, len(valid_g))
         self.debug.append(dict(tok_fts=tok.detach(), geom7=geom7.detach(), lens=lens.copy(), cen=cen.detach(), env_of_group=(valid_g // n_max).copy(), B=B, P=P,
                                img_ix=None if image_ft_ix is None else image_ft_ix.detach().float(), img_mean=None if image_ft_mean is None else image_ft_mean.detach().float(),
                                gt=None if self.cur["gt"] is None else self.cur["gt"].clone(), pairs=None))
@@ -279,25 +285,45 @@ class FFTrainer:
             self._gt_dev = (pts, cap, torch.tensor([len(x) for x in self.gt_xyz], dtype=torch.int32, device=dev))
         return self._gt_dev
 
-    def _label_segments(self, ops, pools, envs, slots_h, row_base, order, counts, valid_g, n_max):
+    def _gt_labels_device(self, dev):
+        if self._gt_lab_dev is None:
+            cap = max(len(x) for x in self.gt_label)
+            lo = min(int(np.min(x)) for x in self.gt_label)
+            hi = max(int(np.max(x)) for x in self.gt_label)
+            lab = torch.full((len(self.gt_label), cap), 0, dtype=torch.int64, device=dev)
+            for e, x in enumerate(self.gt_label):
+                lab[e, :len(x)] = torch.from_numpy(np.ascontiguousarray(x, np.int64)).to(dev) - lo
+            self._gt_lab_dev = (lab, lo, hi - lo + 1)
+        return self._gt_lab_dev
+
+    def _label_segments(self, ops, pools, envs, slots_h, row_base, order, grp_of_tok, n_groups):
+        """GT instance id of every 2D segment (PRE-FF:977-983): k = 1 nearest GT point of each patch (`d3d_knn[_chunked]` over the GT cloud),
+        then the majority label of the segment's patches, ties to the SMALLEST label (`unique_vals[counts.argmax()]`: torch.unique is
+        sorted, argmax takes the first maximum).  Everything stays on the device (round 5; rounds 3-4 read the indices back and voted
+        with numpy: a synchronisation + 128 Python iterations per view): one sorted `unique` over (group, label) keys, the per-group
+        maximum count, and the smallest key among the entries that reach it.  -> (n_groups,) int64 on the device."""
         dev = pools.rows_pos.device
         B, P = order.shape
         pts, cap, n_pts = self._gt_device(dev)
+        lab, lo, L = self._gt_labels_device(dev)
         rows = torch.from_numpy((np.asarray(row_base, np.int64)[:, None] + order).astype(np.int64)).to(dev)       # (B, P) rows in (label, patch) order
-        q = torch.stack([pools.rows_pos[int(slots_h[j])].index_select(0, rows[j]) for j in range(B)]).contiguous()   # (B, P, 3) world positions
+        slots_d = torch.as_tensor(np.asarray(slots_h, np.int64)).to(dev)
+        q = pools.rows_pos[slots_d[:, None], rows].contiguous()                                                     # (B, P, 3) world positions
         i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
-        sel = pts if len(envs) == pts.shape[0] else pts.index_select(0, torch.tensor(list(envs), device=dev))
-        npts = n_pts if len(envs) == pts.shape[0] else n_pts.index_select(0, torch.tensor(list(envs), device=dev))
+        all_envs = len(envs) == pts.shape[0] and list(envs) == list(range(len(envs)))
+        env_d = None if all_envs else torch.tensor(list(envs), device=dev)
+        sel = pts if all_envs else pts.index_select(0, env_d)
+        npts = n_pts if all_envs else n_pts.index_select(0, env_d)
         _d2, idx = ops.knn(sel.contiguous(), cap * 3, npts.contiguous(), q, P * 3, i32([P] * B), i32([1] * B), B, P, 1)
-        idx_h = idx.view(B, P).cpu().numpy()
-        out = np.zeros(len(valid_g), np.int64)
-        off = np.concatenate([np.zeros((B, 1), np.int64), np.cumsum(counts, 1)], 1)
-        for gi, g in enumerate(valid_g):
-            j, s = divmod(int(g), n_max)
-            lab = np.asarray(self.gt_label[envs[j]])[idx_h[j, off[j, s]:off[j, s + 1]]]
-            vals, cnt = np.unique(lab, return_counts=True)
-            out[gi] = vals[cnt.argmax()]                                                               # unique_vals[counts.argmax()]
-        return out
+        lab_sel = lab if all_envs else lab.index_select(0, env_d)
+        plab = torch.gather(lab_sel, 1, idx.view(B, P).long()).reshape(-1)                                          # label (minus lo) of every patch
+        key = grp_of_tok.long() * L + plab
+        uk, cnt = torch.unique(key, return_counts=True)                                                             # sorted: groups ascending, labels ascending
+        g = uk // L
+        best = torch.zeros(n_groups, dtype=cnt.dtype, device=dev).scatter_reduce_(0, g, cnt, "amax")
+        big = torch.iinfo(torch.int64).max
+        first = torch.full((n_groups,), big, dtype=torch.int64, device=dev).scatter_reduce_(0, g, torch.where(cnt == best[g], uk, torch.full_like(uk, big)), "amin")
+        return first % L + lo
 
     # ---- hook 2: merge proposals ------------------------------------------------------------------------------------------------------------
     @torch.enable_grad()
@@ -316,7 +342,7 @@ class FFTrainer:
         if c["gt"] is None:
             no = torch.zeros((logits.shape[0],), device=logits.device)
             return torch.stack([1.0 - no, no], -1)                                                     # argmax = "do not merge" for every proposal
-        gt3 = torch.stack([self._slot_gt(int(s), pools)[int(i)] for s, i in zip(slot_of_pair.tolist(), pair_inst.tolist())]).to(dev)
+        gt3 = self._gt_rows(pools)[slot_of_pair.long(), pair_inst.long()]                              # (PRE-FF:1031: global_gt_instance_ids[gt_inds])
         target = (gt3 == c["gt"].index_select(0, g)).long()
         for j in range(n_envs):                                                                        # one cross-entropy per (environment, view)
             sel = pe == j
@@ -327,24 +353,24 @@ class FFTrainer:
         self.debug[-1]["pairs"] = dict(f3=f3.detach(), p3=p3.detach(), g=g.clone(), target=target.clone(), pe=pe.clone())
         return torch.stack([1.0 - target.float(), target.float()], -1)                                 # argmax = the ground-truth decision
 
-    def _slot_gt(self, slot, pools):
-        cap = pools.inst_pos.shape[1]
-        t = self.gt_ids_of_slot.get(slot)
-        if t is None or t.shape[0] < cap:
-            n = torch.full((cap,), -1, dtype=torch.int64)
+    def _gt_rows(self, pools) -> torch.Tensor:
+        """(slots, m_cap) GT ids next to the instance pool; grown with it."""
+        S, cap = pools.inst_pos.shape[0], pools.inst_pos.shape[1]
+        t = self.gt_rows
+        if t is None or t.shape[0] < S or t.shape[1] < cap or t.device != pools.inst_pos.device:
+            n = torch.full((S, cap), -1, dtype=torch.int64, device=pools.inst_pos.device)
             if t is not None:
-                n[: t.shape[0]] = t
-            self.gt_ids_of_slot[slot] = t = n
+                n[: min(S, t.shape[0]), : min(cap, t.shape[1])] = t[: min(S, t.shape[0]), : min(cap, t.shape[1])].to(n.device)
+            self.gt_rows = t = n
         return t
 
     def new_instances(self, pools, new_slots, new_rows, new_src):
-        """Instance rows created by this view: remember their GT id (PRE-FF:1091-1097)."""
-        if self.cur["gt"] is None:
+        """Instance rows created by this view: remember their GT id (PRE-FF:1091-1097).  One scatter on the device."""
+        if self.cur["gt"] is None or not len(new_rows):
             return
-        gt = self.cur["gt"].cpu()
-        inv = self.cur["inv"].cpu()
-        for s, r, src in zip(new_slots, new_rows, new_src):
-            self._slot_gt(int(s), pools)[int(r)] = gt[int(inv[int(src)])]
+        dev = self.cur["gt"].device
+        idx = torch.tensor([list(new_slots), list(new_rows), list(new_src)], dtype=torch.int64, device=dev)
+        self._gt_rows(pools)[idx[0], idx[1]] = self.cur["gt"].index_select(0, self.cur["inv"].index_select(0, idx[2]))
 
     # ---- PRE-FF:1302-1345 ---------------------------------------------------------------------------------------------------------------------
     @torch.enable_grad()
