@@ -230,7 +230,10 @@ class Dynam3D_VLN(RefreshOnChange):
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # D3D_LLAVA_STREAM_PRIO=-1: the llava tower's stream at HIGH priority, so that its large grids win the dispatcher over the
+            # token builder's small float32 kernels that run beside it (the builder has ~1.3 ms of slack under the tower).  Experiment knob.
+            prio = int(__import__("os").environ.get("D3D_LLAVA_STREAM_PRIO", "0"))
+            self._side = torch.cuda.Stream(device=self.device, priority=prio)
         return self._side
 
     # ---- reference surface -----------------------------------------------------------------------------
