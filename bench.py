@@ -477,9 +477,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "phi3.gate_up_proj GEMM + fused SwiGLU (sum(S_b) x 3072 x 16384, bf16): k_gemm_nt_256<bf16,SwiGLU> on the full rounds (+ k_gemm_nt<bf16,SwiGLU> on the last rows when the last round is at most half full); avg_launch_ms covers the whole projection", "gemm_rows_launched_last_step": rows_gemm, "mean_real_tokens_per_launch": round(gu_flops / (2.0 * l.hidden * 2 * l.mlp), 1),
                          "algorithmic_gflop_per_launch_mean": round(gu_flops / 1e9, 2), "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                         "launches_timed": n_gu, "avg_launch_ms": round(ms_gu, 4), "avg_launch_ms_event_bracket": round(ms_gu_raw, 4),
+                         "launches_timed": n_gu, "timed_every_nth_layer": int(getattr(net.llm, "TIME_EVERY", 1)), "avg_launch_ms": round(ms_gu, 4), "avg_launch_ms_event_bracket": round(ms_gu_raw, 4),
                          "event_pair_overhead_ms": round(ms_empty, 4),
-                         "accounting": "achieved = (sum over the timed launches of 2 * real_tokens * 3072 * 16384) / (sum of their HIP-event durations - event-pair overhead); "
+                         "accounting": "achieved = (sum over the timed launches of 2 * real_tokens * 3072 * 16384) / (sum of their HIP-event durations - event-pair overhead); every 4th layer's launch of every timed step is event-timed (D3D_BENCH_TIME_EVERY=1: all 31 per step -- same fraction, 0.3-0.5 ms more instrumentation inside the step); "
                                        "step_* = mean over the timed steps of the algorithmic FLOPs at that step's own S_b",
                          "step_total_tflop": round(fl["total"] / 1e12, 2), "step_frac_of_peak": round(fl["total"] / (ms * 1e-3) / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4),
                          "step_flop_split_tflop": {k: round(v / 1e12, 3) for k, v in fl.items() if k != "total"}},

@@ -361,6 +361,7 @@ class Phi3Decoder:
                     sched=sched)
 
     ATTN_SCHED = os.environ.get("D3D_ATTN_SCHED", "0") == "1"
+    TIME_EVERY = max(1, int(os.environ.get("D3D_BENCH_TIME_EVERY", "4")))
 
     # rotate the queries inside the attention kernel (d3d_flash_attention_v3_rope_q) when the backend can; D3D_FUSE_ROPE_Q=0: in place, with the keys
     FUSE_ROPE_Q = os.environ.get("D3D_FUSE_ROPE_Q", "1") != "0"
@@ -391,8 +392,11 @@ class Phi3Decoder:
             a, x = a[ctx["last_rows"]].contiguous(), x[ctx["last_rows"]].contiguous()
         x = D.linear(a, L["o_w"], None, residual=x)
         h = D.rms_norm(x, L["n2"], c.rms_eps)
-        if h.shape[0] == Tp:
-            with TIMER.range("phi3.gate_up_proj", rows=ctx["cu_h"][-1]):    # (bench.py's roofline launch: the full-row GEMMs only)
+        if h.shape[0] == Tp and li % self.TIME_EVERY == 0:
+            # bench.py's roofline launch (full-row GEMMs only), HIP-event timed in every TIME_EVERY-th layer: an event pair costs ~6 us on
+            # the stream and the bracket below as much again -- timing all 31 full-row launches of a step put 0.4 ms of instrumentation
+            # into the step it measures (D3D_BENCH_TIME_EVERY=1: every layer, as rounds 1-4 did)
+            with TIMER.range("phi3.gate_up_proj", rows=ctx["cu_h"][-1]):
                 act = D.linear_swiglu(h, L["gu_w"], self.interleave_gu)
             with TIMER.range("phi3.event_pair_overhead"):                   # an EMPTY bracket right behind it: what two event records
                 pass                                                        # cost on this stream at this point (bench.py subtracts it)
