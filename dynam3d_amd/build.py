@@ -24,6 +24,7 @@ HIP_SOURCES = [
     ("train_kernels.hip", ["-ffp-contract=off"]),
     ("f32_kernels.hip", ["-ffp-contract=off"]),
     ("f32x3_kernels.hip", ["-ffp-contract=off"]),
+    ("verify_f32_kernels.hip", ["-ffp-contract=off"]),
     ("gemm_kernels.hip", ["-ffp-contract=fast"]),
     ("attn3_kernels.hip", ["-ffp-contract=fast"]),
     ("decode_attn_kernels.hip", ["-ffp-contract=fast"]),

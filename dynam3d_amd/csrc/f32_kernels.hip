@@ -21,7 +21,7 @@ namespace {
 
 using float4v = __attribute__((ext_vector_type(4))) float;
 
-enum EpiF32 : int { F_NONE = 0, F_BIAS = 1, F_BIAS_GELU = 2, F_BIAS_RES = 3 };
+enum EpiF32 : int { F_NONE = 0, F_BIAS = 1, F_BIAS_GELU = 2, F_BIAS_RES = 3, F_BIAS_QGELU = 4, F_RES = 5 };    // 4 / 5: the float32 verification towers (QuickGELU; bias-free residual)
 
 constexpr int FBK = 16, FPITCH = 24;   // LDS row pitch 24 floats (96 B): ds_read_b128 of lane (row i, k-group g) hits 16-byte slot
                                        // (6 i + g) % 16 -- conflict-free for every 16-lane service group
@@ -143,7 +143,7 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ W, float* __re
             const int n = col0 + wc * WAVE_T + j * 16 + fg * 4;
             if (n >= N) continue;
             float4v v = acc[i][j];
-            if constexpr (EPI != F_NONE) {
+            if constexpr (EPI != F_NONE && EPI != F_RES) {
                 const float4 b = *reinterpret_cast<const float4*>(bias + n);
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
             }
@@ -151,7 +151,11 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ W, float* __re
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
             }
-            if constexpr (EPI == F_BIAS_RES) {
+            if constexpr (EPI == F_BIAS_QGELU) {      // clip/model.py:162-164: x * sigmoid(1.702 x)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-1.702f * v[r]));
+            }
+            if constexpr (EPI == F_BIAS_RES || EPI == F_RES) {
                 const float4 rr = *reinterpret_cast<const float4*>(residual + (int64_t)m * ldc + n);
                 v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
             }
@@ -295,8 +299,8 @@ int32_t d3d_gemm_nt_f32(const float* A, const float* W, float* C, const float* b
         d3d_set_error_("d3d_gemm_nt_f32: need N % 4 == 0, K % 16 == 0 (zero-pad), lda / ldw / ldc % 4 == 0");
         return D3D_EINVAL;
     }
-    if ((epilogue != F_NONE && !bias) || (epilogue == F_BIAS_RES && !residual)) {
-        d3d_set_error_("d3d_gemm_nt_f32: epilogue needs bias (1, 2, 3) / residual (3)");
+    if ((epilogue != F_NONE && epilogue != F_RES && !bias) || ((epilogue == F_BIAS_RES || epilogue == F_RES) && !residual)) {
+        d3d_set_error_("d3d_gemm_nt_f32: epilogue needs bias (1, 2, 3, 4) / residual (3, 5)");
         return D3D_EINVAL;
     }
     // 128 x 128 tiles when they cover at least half the CUs, 64 x 64 tiles otherwise (see k_gemm_f32)
@@ -319,8 +323,10 @@ int32_t d3d_gemm_nt_f32(const float* A, const float* W, float* C, const float* b
         D3D_F32_CASE(F_BIAS)
         D3D_F32_CASE(F_BIAS_GELU)
         D3D_F32_CASE(F_BIAS_RES)
+        D3D_F32_CASE(F_BIAS_QGELU)
+        D3D_F32_CASE(F_RES)
         default:
-            d3d_set_error_("d3d_gemm_nt_f32: epilogue 0 none, 1 bias, 2 bias + GELU, 3 bias + residual");
+            d3d_set_error_("d3d_gemm_nt_f32: epilogue 0 none, 1 bias, 2 bias + GELU, 3 bias + residual, 4 bias + QuickGELU, 5 residual");
             return D3D_EINVAL;
     }
 #undef D3D_F32_CASE

@@ -1,8 +1,9 @@
-"""Dense primitive dispatch for the towers.  Each primitive names the HIP kernel that implements it on
-gfx950 (csrc/gemm_kernels.hip, attn_kernels.hip, dense_kernels.hip); primitives that do not have a
-hand-written kernel yet run on PyTorch-ROCm's MFMA libraries (hipBLASLt GEMM / SDPA flash attention),
-which the north_star allows for plain library contractions.  `BACKEND` records the choice per primitive
-so the benchmark can report exactly what ran.
+"""Dense primitive dispatch for the towers.  Each primitive names the hand-written gfx950 kernel that implements it
+(csrc/gemm_kernels.hip, attn3_kernels.hip, dense_kernels.hip, tower_kernels.hip).  On a CUDA tensor the HIP kernel is the
+ONLY path by default (`STRICT = True`: a shape / dtype without a kernel raises `DenseFallbackError`); the PyTorch
+expression beside each primitive exists for CPU tensors (the CPU suite's host-logic path) and behind the explicit
+opt-out `allow_fallback()` (toy test configurations, `bench.py --hip-dense` A/B baselines), counted per primitive.
+`BACKEND` records what each primitive is bound to so the benchmark line reports exactly what ran.
 
 Shapes: activations are row-major (tokens, features); weights are [out, in] like nn.Linear.
 """
@@ -88,6 +89,13 @@ def enable_hip_kernels(which: Sequence[str] = ("all",)):
     return dict(BACKEND)
 
 
+def _f32(x: torch.Tensor) -> bool:
+    """The float32 VERIFICATION MODE (csrc/verify_f32_kernels.hip): a float32 CUDA tensor on the HIP backend runs the float32 twin of the
+    primitive's kernel -- same host wiring as the 16-bit product path, float32 arithmetic, so that north_star's 1e-3 against the float32
+    oracle can be asserted on it under strict dispatch (towers built with dtype=float32)."""
+    return x.is_cuda and x.dtype == torch.float32 and _hip is not None
+
+
 def _act(y, act):
     if act is None:
         return y
@@ -105,6 +113,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: Opt
     if BACKEND["linear"] == "hip" and x.is_cuda and _hip.gemm_ok(x, w):
         _hit("linear")
         return _hip.linear(x, w, b, act, residual)
+    if BACKEND["linear"] == "hip" and _f32(x) and _hip.gemm_f32_ok(x, w):
+        _hit("linear")
+        return _hip.linear_f32(x, w, b, act, residual)
     _miss("linear", x, f"backend {BACKEND['linear']}, x {tuple(x.shape)} {x.dtype}, w {tuple(w.shape)} {w.dtype}")
     y = _act(F.linear(x, w, b), act)
     return y if residual is None else y + residual.reshape(y.shape)
@@ -116,6 +127,9 @@ def linear_swiglu(x: torch.Tensor, w_gate_up: torch.Tensor, interleaved: bool) -
     if interleaved and BACKEND["linear"] == "hip" and x.is_cuda and _hip.gemm_ok(x, w_gate_up):
         _hit("linear_swiglu")
         return _hip.linear_swiglu(x, w_gate_up)
+    if not interleaved and BACKEND["linear"] == "hip" and _f32(x) and _hip.gemm_f32_ok(x, w_gate_up):
+        _hit("linear_swiglu")
+        return _hip.swiglu_f32(_hip.linear_f32(x, w_gate_up, None, None))
     _miss("linear_swiglu", x, f"interleaved {interleaved}, x {tuple(x.shape)} {x.dtype}, w {tuple(w_gate_up.shape)}")
     gu = F.linear(x, w_gate_up)
     if interleaved:
@@ -145,6 +159,10 @@ def vit_embed(pixels: torch.Tensor, patch_w: torch.Tensor, cls: torch.Tensor, po
         rows = _hip.patchify(pixels, patch, patch_w.shape[1], dt)
         x = linear(rows, patch_w, None)
         return _hip.vit_embed_ln(x, cls, pos, ln_w, ln_b, B, eps)
+    if BACKEND["vit_embed"] == "hip" and pixels.is_cuda and dt == torch.float32 and _hip.gemm_f32_ok(patch_w[:1], patch_w):
+        _hit("vit_embed")
+        x = linear(_hip.patchify_f32(pixels, patch, patch_w.shape[1]), patch_w, None)
+        return _hip.vit_embed_ln_f32(x, cls, pos, ln_w, ln_b, B, eps)
     _miss("vit_embed", pixels, f"dtype {dt}, patch_w {tuple(patch_w.shape)}")
     pt = pixels.to(dt).view(B, 3, G, patch, G, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * G * G, K)
     x = F.linear(pt, patch_w[:, :K]).view(B, G * G, -1)
@@ -157,6 +175,9 @@ def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) ->
     if BACKEND["layer_norm"] == "hip" and x.is_cuda and _hip.norm_ok(x):
         _hit("layer_norm")
         return _hip.layer_norm(x, w, b, eps)
+    if BACKEND["layer_norm"] == "hip" and _f32(x) and x.shape[-1] % 4 == 0 and x.shape[-1] <= 3072:
+        _hit("layer_norm")
+        return _hip.layer_norm_f32(x, w, b, eps)
     _miss("layer_norm", x, f"x {tuple(x.shape)} {x.dtype}")
     return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps).to(x.dtype)
 
@@ -165,6 +186,9 @@ def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     if BACKEND["rms_norm"] == "hip" and x.is_cuda and _hip.norm_ok(x):
         _hit("rms_norm")
         return _hip.rms_norm(x, w, eps)
+    if BACKEND["rms_norm"] == "hip" and _f32(x) and x.shape[-1] % 4 == 0:
+        _hit("rms_norm")
+        return _hip.rms_norm_f32(x, w, eps)
     _miss("rms_norm", x, f"x {tuple(x.shape)} {x.dtype}")
     xf = x.float()
     xh = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype)          # HF Phi3RMSNorm: weight * x_hat.to(input_dtype)
@@ -185,12 +209,15 @@ def attention_qkv(qkv: torch.Tensor, n_heads: int, causal: bool) -> torch.Tensor
     if BACKEND["attention"] == "hip" and qkv.is_cuda and Ht == 3 * n_heads and _hip.attention_ok(qkv, hd):
         _hit("attention")
         return _hip.attention_qkv(qkv, n_heads, causal)
+    if BACKEND["attention"] == "hip" and _f32(qkv) and Ht == 3 * n_heads and hd in (64, 96) and qkv.is_contiguous():
+        _hit("attention")
+        return _hip.attention_qkv_f32(qkv, n_heads, causal)
     return attention(qkv[:, :, :n_heads], qkv[:, :, n_heads:2 * n_heads], qkv[:, :, 2 * n_heads:], causal)
 
 
 def packed_ok(dtype, head_dim: int) -> bool:
     """True when the packed (variable-length, no padding) decoder path is available: HIP rope + flash attention."""
-    return (BACKEND["attention"] == "hip" and BACKEND["rope"] == "hip" and dtype in (torch.bfloat16, torch.float16)
+    return (BACKEND["attention"] == "hip" and BACKEND["rope"] == "hip" and dtype in (torch.bfloat16, torch.float16, torch.float32)
             and head_dim in (64, 96) and (head_dim // 2) % 8 == 0)
 
 
@@ -205,6 +232,9 @@ def attention_packed(qkv3: torch.Tensor, n_heads: int, causal: bool, cu_seqlens:
     """`rope_q` = (cos, sin): the buffer's queries are NOT rotated yet, the kernel rotates them (see `can_fuse_rope_q`).
     `sched`: workgroup table from `attention_schedule` (one query block per workgroup, heaviest first)."""
     _hit("attention")
+    if qkv3.dtype == torch.float32:
+        assert rope_q is None and sched is None          # (the float32 mode rotates q and k in place: `can_fuse_rope_q(float32)` is False)
+        return _hip.attention_packed_f32(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid, window, out)
     return _hip.attention_packed(qkv3, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid, window, out, rope_q, sched)
 
 
@@ -212,7 +242,9 @@ def attention_schedule(lens, n_heads: int, device) -> torch.Tensor:
     return torch.from_numpy(_hip.attention_schedule(lens, n_heads)).to(device)
 
 
-def can_fuse_rope_q() -> bool:
+def can_fuse_rope_q(dtype=None) -> bool:
+    if dtype == torch.float32:
+        return False
     return BACKEND["attention"] == "hip" and BACKEND["rope"] == "hip" and _hip is not None and _hip.can_fuse_rope_q()
 
 
@@ -224,7 +256,7 @@ def rope_qk_(qkv: torch.Tensor, n_rot_heads: int, cos: torch.Tensor, sin: torch.
     """Rotate the first `n_rot_heads` heads (q heads then k heads) of the fused projection qkv (B,S,Htot,hd);
     in place on the HIP backend (one pass over q,k instead of slice/float/cat round trips)."""
     B, S, Ht, hd = qkv.shape
-    if (BACKEND["rope"] == "hip" and qkv.is_cuda and qkv.is_contiguous() and qkv.dtype in (torch.bfloat16, torch.float16)
+    if (BACKEND["rope"] == "hip" and qkv.is_cuda and qkv.is_contiguous() and qkv.dtype in (torch.bfloat16, torch.float16, torch.float32)
             and (hd // 2) % 8 == 0):
         _hit("rope")
         _hip.rope_inplace(qkv.view(B * S, Ht * hd), cos, sin, S, n_rot_heads, hd)
@@ -246,6 +278,9 @@ def swiglu(gu: torch.Tensor) -> torch.Tensor:
     if BACKEND["swiglu"] == "hip" and gu.is_cuda and gu.dtype in (torch.bfloat16, torch.float16) and gu.shape[-1] % 16 == 0:
         _hit("swiglu")
         return _hip.swiglu(gu)
+    if BACKEND["swiglu"] == "hip" and _f32(gu) and gu.shape[-1] % 8 == 0:
+        _hit("swiglu")
+        return _hip.swiglu_f32(gu)
     _miss("swiglu", gu, f"gu {tuple(gu.shape)} {gu.dtype}")
     g, u = gu.chunk(2, dim=-1)
     return u * F.silu(g)

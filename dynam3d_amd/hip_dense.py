@@ -30,6 +30,14 @@ _lib.register("d3d_phi3_decode_status", [vp])
 _lib.register("d3d_patchify", [vp, vp, i32, i32, i32, i32, i32, vp])
 _lib.register("d3d_vit_embed_ln", [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp])
 _lib.register("d3d_assemble_prompt", [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp])
+# float32 verification mode (csrc/verify_f32_kernels.hip; GEMMs / LayerNorm: d3d_gemm_nt_f32 / d3d_layer_norm_f32, registered in f32_ops)
+_lib.register("d3d_attention_f32", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp])
+_lib.register("d3d_rms_norm_f32", [vp, vp, vp, i32, i32, i64, i64, f32, vp])
+_lib.register("d3d_rope_inplace_f32", [vp, vp, vp, i32, i32, i32, i32, i64, vp, vp])
+_lib.register("d3d_swiglu_f32", [vp, vp, i64, i32, vp])
+_lib.register("d3d_patchify_f32", [vp, vp, i32, i32, i32, i32, vp])
+_lib.register("d3d_vit_embed_ln_f32", [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp])
+_lib.register("d3d_assemble_prompt_f32", [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp])
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -151,7 +159,11 @@ class HipDense:
         return self._norm(x, w, None, eps, True)
 
     def rope_inplace(self, qkv2d, cos, sin, S, n_rot_heads, hd, pos=None):
-        """qkv2d (rows, >= n_rot_heads*hd) bf16/fp16, rotated in place; position = pos[row] if given else row % S."""
+        """qkv2d (rows, >= n_rot_heads*hd) bf16 / fp16 (float32: the verification mode's kernel), rotated in place; position = pos[row] if
+        given else row % S."""
+        if qkv2d.dtype == torch.float32:
+            _lib.check(self.lib.d3d_rope_inplace_f32(_p(qkv2d), _p(cos), _p(sin), qkv2d.shape[0], S, n_rot_heads, hd, qkv2d.stride(0), _p(pos), self._stream()))
+            return
         _lib.check(self.lib.d3d_rope_inplace(_p(qkv2d), _p(cos), _p(sin), qkv2d.shape[0], S, n_rot_heads, hd, qkv2d.stride(0), _p(pos),
                                              0 if qkv2d.dtype == torch.bfloat16 else 1, self._stream()))
 
@@ -222,6 +234,101 @@ class HipDense:
         """qkv (T, 3*H*64) f32 packed sets -> (T, H*64) f32 (rows outside the queried range are zero)."""
         out = torch.zeros((qkv.shape[0], n_heads * 64), dtype=torch.float32, device=qkv.device)
         _lib.check(self.lib.d3d_set_attention(_p(qkv), _p(set_off), n_sets, n_heads, max_len, q_rows, _p(out), self._stream()))
+        return out
+
+    # ---- float32 verification mode (csrc/verify_f32_kernels.hip + the float32-MFMA GEMM / LayerNorm of f32_kernels.hip) -------------------
+    F32_EPI = dict(none=0, bias=1, bias_gelu=2, bias_res=3, bias_quick_gelu=4, res=5)
+
+    @staticmethod
+    def gemm_f32_ok(x, w):
+        K = x.shape[-1]
+        return (x.dtype == torch.float32 and w.dtype == torch.float32 and w.shape[0] % 4 == 0 and K % 16 == 0 and K == w.shape[1]
+                and x.stride(-1) == 1 and w.is_contiguous())
+
+    def linear_f32(self, x, w, b, act, residual=None):
+        """act(x w^T + b) [+ residual] in float32 on v_mfma_f32_16x16x4_f32 (d3d_gemm_nt_f32: an exact float32 multiply-add chain)."""
+        from . import f32_ops  # noqa: F401  (registers d3d_gemm_nt_f32 / d3d_layer_norm_f32)
+        x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
+        if x2.stride(-1) != 1 or x2.stride(0) % 4:
+            x2 = x2.contiguous()
+        M, K = x2.shape
+        N = w.shape[0]
+        if residual is not None:
+            residual = residual.reshape(-1, N)
+            if not residual.is_contiguous():
+                residual = residual.contiguous()
+        if act is None:
+            epi = ("bias_res" if b is not None else "res") if residual is not None else ("bias" if b is not None else "none")
+        else:
+            assert residual is None and b is not None
+            epi = {"quick_gelu": "bias_quick_gelu", "gelu": "bias_gelu"}[act]
+        if b is not None and b.dtype != torch.float32:
+            b = b.float()
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.d3d_gemm_nt_f32(_p(x2), _p(w), _p(y), _p(b), _p(residual), M, N, K, x2.stride(0), K, N, self.F32_EPI[epi], self._stream()))
+        return y
+
+    def layer_norm_f32(self, x, w, b, eps):
+        from . import f32_ops  # noqa: F401
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(-1) != 1 or x2.stride(0) % 4:
+            x2 = x2.contiguous()
+        y = torch.empty(x2.shape, dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.d3d_layer_norm_f32(_p(x2), None, _p(w), _p(b), _p(y), x2.shape[0], x2.shape[1], x2.stride(0), 0, x2.shape[1], eps, 0, self._stream()))
+        return y.view(x.shape)
+
+    def rms_norm_f32(self, x, w, eps):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(-1) != 1 or x2.stride(0) % 4:
+            x2 = x2.contiguous()
+        y = torch.empty(x2.shape, dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.d3d_rms_norm_f32(_p(x2), _p(w), _p(y), x2.shape[0], x2.shape[1], x2.stride(0), x2.shape[1], eps, self._stream()))
+        return y.view(x.shape)
+
+    def swiglu_f32(self, gu):
+        gu2 = gu.reshape(-1, gu.shape[-1]).contiguous()
+        I = gu2.shape[1] // 2
+        out = torch.empty((gu2.shape[0], I), dtype=torch.float32, device=gu.device)
+        _lib.check(self.lib.d3d_swiglu_f32(_p(gu2), _p(out), gu2.shape[0], I, self._stream()))
+        return out
+
+    def patchify_f32(self, pixels, patch, Kp):
+        px = pixels.contiguous()
+        B, _, S, _ = px.shape
+        G = S // patch
+        out = torch.empty((B * G * G, Kp), dtype=torch.float32, device=px.device)
+        _lib.check(self.lib.d3d_patchify_f32(_p(px), _p(out), B, S, patch, Kp, self._stream()))
+        return out
+
+    def vit_embed_ln_f32(self, patch_rows, cls, pos, ln_w, ln_b, B, eps):
+        L, D = pos.shape
+        out = torch.empty((B, L, D), dtype=torch.float32, device=patch_rows.device)
+        _lib.check(self.lib.d3d_vit_embed_ln_f32(_p(patch_rows.contiguous()), _p(cls.contiguous()), _p(pos.contiguous()), _p(ln_w), _p(ln_b), _p(out), B, L, D,
+                                                 eps, self._stream()))
+        return out
+
+    def assemble_prompt_f32(self, desc, embed, patch_feat, patch_pos, inst, zone, rows):
+        D = embed.shape[1]
+        for t in (embed, patch_feat, patch_pos, inst, zone):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[-1] == D, (t.dtype, t.shape)
+        out = torch.empty((rows, D), dtype=torch.float32, device=embed.device)
+        _lib.check(self.lib.d3d_assemble_prompt_f32(_p(desc), _p(embed), _p(patch_feat), _p(patch_pos), _p(inst), _p(zone), _p(out), rows, D, self._stream()))
+        return out
+
+    def attention_qkv_f32(self, qkv, n_heads, causal, window=0):
+        B, S, Ht, hd = qkv.shape
+        out = torch.empty((B, S, n_heads, hd), dtype=torch.float32, device=qkv.device)
+        _lib.check(self.lib.d3d_attention_f32(_p(qkv), _p(out), B, S, n_heads, hd, Ht * hd, S * Ht * hd, 0, n_heads, 2 * n_heads, 1 if causal else 0, S, None,
+                                              window, self._stream()))
+        return out
+
+    def attention_packed_f32(self, qkv, n_heads, causal, cu_seqlens, n_seq, max_len, n_valid=None, window=0, out=None):
+        T, Ht, hd = qkv.shape
+        if out is None:
+            out = torch.zeros((T, n_heads, hd), dtype=torch.float32, device=qkv.device)
+        assert out.shape == (T, n_heads, hd) and out.dtype == torch.float32 and out.is_contiguous()
+        _lib.check(self.lib.d3d_attention_f32(_p(qkv), _p(out), n_seq, max_len, n_heads, hd, Ht * hd, 0, 0, n_heads, 2 * n_heads, 1 if causal else 0, max_len,
+                                              _p(cu_seqlens), window, self._stream()))
         return out
 
     @staticmethod

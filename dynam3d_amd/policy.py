@@ -366,6 +366,23 @@ class Dynam3D_VLN(RefreshOnChange):
                 return self._assemble_packed(patch_feat, patch_pos, inst_tok, zone_tok, ni, nz, instructions, B, V)
             return self._assemble_rows(patch_feat, patch_pos, inst_tok, zone_tok, ni, nz, instructions, B, V, return_rows)
 
+    @torch.no_grad()
+    def advance_memory(self, observations, agent_positions, agent_heading_angles, grid, depth_scale=(0.0, 10.0), delete_old_features=True,
+                       num_of_views=1, patch_segm=None):
+        """One step of the 3D memory only -- frustum delete + update (VLN-POL:349-354) -- on GIVEN CLIP grid features `grid` (B*V, 576, 768)
+        instead of the image tower's: brings the memory to a warm operating point that does not depend on 16-bit tower arithmetic
+        (bench.py's golden parity point, tests).  The depth path is `build_inputs`'s."""
+        ff, V = self.feature_fields, num_of_views
+        B = ff.batch_size
+        depth = observations["depth"].to(self.device, torch.float32)
+        depth24 = self._depth24(depth, V, (0.0, 10.0))
+        if delete_old_features:
+            dfull = self.ops.preprocess_depth(depth[..., 0], *depth_scale).view(B, V, depth.shape[1], depth.shape[2])
+            ff.delete_old_features_from_camera_frustum(dfull, agent_positions, agent_heading_angles, num_of_views=V)
+        grid = grid.to(self.device)
+        ff.update_feature_fields(depth24, grid.view(B, V, ff.P, -1), observations["rgb"].to(self.device), agent_positions, agent_heading_angles,
+                                 num_of_views=V, patch_segm=patch_segm)
+
     PROMPT_HEAD = "<|user|>\n"                                    # VLN-POL:436
 
     def _prompt_text(self, b, instructions):
@@ -408,6 +425,27 @@ class Dynam3D_VLN(RefreshOnChange):
             x = D._hip.assemble_prompt(torch.from_numpy(table.astype(np.uint32).view(np.int32)).to(self.device), emb_w,
                                         patch_feat.reshape(B * P, -1).contiguous(), patch_pos.reshape(B * P, -1).contiguous(),
                                         inst_tok.contiguous(), zone_tok.contiguous(), Tp)
+            self.last_lengths = lengths
+            self.last_counts = dict(Ni=ni, Nz=nz)
+            return x, lengths
+        if (self.ASSEMBLE_KERNEL and patch_feat.is_cuda and D.BACKEND["linear"] == "hip" and dt == torch.float32
+                and all(t.dtype == dt for t in (emb_w, patch_feat, patch_pos, inst_tok, zone_tok))):
+            # float32 verification mode: the same row table through the float32 twin of the kernel
+            desc, lengths = [], []
+            i_off, z_off = 0, 0
+            for b in range(B):
+                h_ids, t_ids = parts[b]
+                desc.append(np.concatenate([np.asarray(h_ids, np.int64), (1 << 28) + b * P + np.arange(P), (2 << 28) + i_off + np.arange(ni[b]),
+                                            (3 << 28) + z_off + np.arange(nz[b]), np.asarray(t_ids, np.int64)]))
+                lengths.append(len(h_ids) + P + ni[b] + nz[b] + len(t_ids))
+                i_off, z_off = i_off + ni[b], z_off + nz[b]
+            T = int(sum(lengths))
+            Tp = (T + 255) // 256 * 256
+            table = np.full(Tp, 7 << 28, np.int64)
+            table[:T] = np.concatenate(desc)
+            x = D._hip.assemble_prompt_f32(torch.from_numpy(table.astype(np.uint32).view(np.int32)).to(self.device), emb_w,
+                                            patch_feat.reshape(B * P, -1).contiguous(), patch_pos.reshape(B * P, -1).contiguous(),
+                                            inst_tok.contiguous(), zone_tok.contiguous(), Tp)
             self.last_lengths = lengths
             self.last_counts = dict(Ni=ni, Nz=nz)
             return x, lengths

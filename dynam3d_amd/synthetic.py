@@ -148,3 +148,13 @@ class ClosedLoopEpisodes:
                 for lst in (self.ids, self.pos, self.head, self.goal, self.path, self.steps):
                     lst.pop(b)
         return dones, infos
+
+
+def bench_point_grid(step: int, batch_size: int = 8, patches: int = 576, dim: int = 768, seed: int = 2206) -> np.ndarray:
+    """Seeded unit-norm CLIP-like grid features of memory-advance step `step`, float16 (B, patches, dim): the numbers both legs of the golden
+    parity point feed to the 3D memory (tests/golden/gen_golden_bench_point.py on the CPU oracle, bench.py / the GPU test on the product),
+    fp16-representable so that the product's fp16 feature store and the oracle's float32 one hold identical values."""
+    rng = np.random.default_rng(seed + 1000 * step)
+    g = rng.standard_normal((batch_size, patches, dim)).astype(np.float32)
+    g /= np.linalg.norm(g, axis=-1, keepdims=True)
+    return g.astype(np.float16)

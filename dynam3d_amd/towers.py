@@ -267,7 +267,7 @@ class Phi3Decoder:
         m = "language_model.model"
         self.embed_w = t(sd[m + ".embed_tokens.weight"])
         # gate/up rows interleaved per 16 for the fused SwiGLU GEMM epilogue (only when the HIP GEMM is active)
-        self.interleave_gu = D.BACKEND["linear"] == "hip" and cfg.mlp % 16 == 0
+        self.interleave_gu = D.BACKEND["linear"] == "hip" and cfg.mlp % 16 == 0 and dtype != torch.float32     # (float32 verification mode: plain rows)
         self.layers = []
         for i in range(cfg.layers):
             p = f"{m}.layers.{i}"
@@ -376,7 +376,7 @@ class Phi3Decoder:
         Tp, Ht = x.shape[0], c.heads + 2 * c.kv_heads
         h = D.rms_norm(x, L["n1"], c.rms_eps)
         qkv = D.linear(h, L["qkv_w"], None)
-        fuse_q = self.FUSE_ROPE_Q and D.can_fuse_rope_q()
+        fuse_q = self.FUSE_ROPE_Q and D.can_fuse_rope_q(self.dtype)
         if fuse_q:
             # keys rotated in place (the KV cache keeps rotated keys), queries rotated inside the attention kernel: half of k_rope's traffic
             D.rope_packed_(qkv[:, c.heads * c.head_dim:], c.kv_heads, c.head_dim, ctx["cos"], ctx["sin"], ctx["pos"])
@@ -396,7 +396,7 @@ class Phi3Decoder:
             # bench.py's roofline launch (full-row GEMMs only), HIP-event timed in every TIME_EVERY-th layer: an event pair costs ~6 us on
             # the stream and the bracket below as much again -- timing all 31 full-row launches of a step put 0.4 ms of instrumentation
             # into the step it measures (D3D_BENCH_TIME_EVERY=1: every layer, as rounds 1-4 did)
-            with TIMER.range("phi3.gate_up_proj", rows=ctx["cu_h"][-1]):
+            with TIMER.range("phi3.gate_up_proj", rows=ctx["cu_h"][-1], rows_launched=Tp):
                 act = D.linear_swiglu(h, L["gu_w"], self.interleave_gu)
             with TIMER.range("phi3.event_pair_overhead"):                   # an EMPTY bracket right behind it: what two event records
                 pass                                                        # cost on this stream at this point (bench.py subtracts it)

@@ -279,7 +279,8 @@ int32_t d3d_mlp768_forward(const void* x_d, int64_t n_rows, int32_t n_in, const 
 /* ---- float32 dense kernels of the 3D-token builder (a7, a9, a11, a14: VLN-FF:134-161, VLN-POL:83-111) ----------------------------
  * The set encoders, the merge discriminator and the prefix MLPs are float32 modules whose decisions are pinned bit for bit by golden
  * trajectories: they run in float32 on v_mfma_f32_16x16x4_f32 (exact f32 multiply-add chain).
- * C[M,N] = epilogue(A[M,K] W[N,K]^T): epilogue 0 none, 1 +bias, 2 +bias GELU(erf), 3 +bias +residual (residual (M,N), row stride ldc).
+ * C[M,N] = epilogue(A[M,K] W[N,K]^T): epilogue 0 none, 1 +bias, 2 +bias GELU(erf), 3 +bias +residual (residual (M,N), row stride ldc),
+ * 4 +bias QuickGELU (clip/model.py:162-164), 5 +residual without bias (Phi-3's bias-free projections) -- 4 / 5 serve the float32 verification towers.
  * K % 16 == 0 (zero-pad operands), N % 4 == 0, strides % 4 == 0. */
 int32_t d3d_gemm_nt_f32(const float* A_d, const float* W_d, float* C_d, const float* bias_d, const float* residual_d, int32_t M, int32_t N,
                         int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t epilogue, void* stream);
@@ -306,6 +307,29 @@ int32_t d3d_linear_smalln_f32(const float* x_d, const float* W_d, const float* b
 int32_t d3d_layer_norm_f32(const float* x_d, const float* residual_d /* optional */, const float* w_d, const float* b_d, float* y_d, int32_t rows,
                            int32_t D, int64_t ldx, int64_t ldr, int64_t ldy, float eps, int32_t gelu, void* stream);
 
+/* ---- FLOAT32 VERIFICATION MODE of the dense towers (a3, a15, a17; csrc/verify_f32_kernels.hip) --------------------------------------
+ * `PolicyConfig(clip_dtype=float32, llava_dtype=float32)` runs the towers' host wiring on float32 kernels under strict dispatch, so that
+ * north_star's "logits within 1e-3 of the reference" is ASSERTED against the float32 oracle on the HIP GEMM / attention / RoPE / norm
+ * wiring (the 16-bit product path sits a ~1.7e-2 noise band from float32 arithmetic, like the reference's own bf16 run).  GEMMs =
+ * d3d_gemm_nt_f32, LayerNorms = d3d_layer_norm_f32; the entries below are the float32 twins of the 16-bit row / attention kernels.
+ * d3d_attention_f32: the SDPA inside llava.generate (VLN-POL:463) and the ViT blocks (clip/model.py:178-180); the buffer contract of
+ * d3d_flash_attention_v3 (fused [q | k | v] head blocks, dense or cu_seqlens-packed, causal, sliding window) with float32 elements. */
+int32_t d3d_attention_f32(const float* qkv_d, float* out_d, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride, int64_t batch_stride,
+                          int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len, const int32_t* cu_seqlens_d, int32_t window,
+                          void* stream);
+/* HF Phi3RMSNorm in float32: y = x * rsqrt(mean(x^2) + eps) * w over rows of D floats (D, strides % 4 == 0) */
+int32_t d3d_rms_norm_f32(const float* x_d, const float* w_d, float* y_d, int32_t rows, int32_t D, int64_t ldx, int64_t ldy, float eps, void* stream);
+/* HF apply_rotary_pos_emb (half split) in float32, in place on the first n_rot_heads heads of every row; tables (positions, head_dim / 2) */
+int32_t d3d_rope_inplace_f32(float* qkv_d, const float* cos_d, const float* sin_d, int32_t rows, int32_t S, int32_t n_rot_heads, int32_t head_dim,
+                             int64_t ld, const int32_t* pos_of_row_d /* optional */, void* stream);
+/* Phi3MLP: out (rows, I) = up * silu(gate) of gate_up (rows, 2 I) = [gate | up] */
+int32_t d3d_swiglu_f32(const float* gate_up_d, float* out_d, int64_t rows, int32_t I, void* stream);
+/* float32 twins of d3d_patchify / d3d_vit_embed_ln / d3d_assemble_prompt (clip/model.py:222-228; VLN-POL:448-456) */
+int32_t d3d_patchify_f32(const float* pixels_d, float* out_d, int32_t B, int32_t S, int32_t patch, int32_t Kp, void* stream);
+int32_t d3d_vit_embed_ln_f32(const float* patch_rows_d, const float* cls_d, const float* pos_d, const float* ln_w_d, const float* ln_b_d, float* y_d,
+                             int32_t B, int32_t L, int32_t D, float eps, void* stream);
+int32_t d3d_assemble_prompt_f32(const uint32_t* desc_d, const float* embed_d, const float* patch_feat_d, const float* patch_pos_d, const float* inst_d,
+                                const float* zone_d, float* out_d, int32_t rows, int32_t D, void* stream);
 /* ---- backward pass of the tcnn CutlassMLP replacement (the Pretrain path trains these networks, PRE-FF:221-243) ----
  * All three GEMMs of a layer are d3d_gemm_nt launches on 16-bit operands:
  *   forward        h_l  = act(h_{l-1} W_l^T)                         epilogue 0 / 7
