@@ -516,6 +516,14 @@ int32_t d3d_flash_attention_v3_sched(const void* qkv, void* out, int32_t B, int3
         d3d_set_error_("d3d_flash_attention_v3_rope_q: rope_cos and rope_sin come together");
         return D3D_EINVAL;
     }
+    // Round 6: launches without a window and without a workgroup table run on the software-pipelined kernel of attn4_kernels.hip
+    // (D3D_ATTN_V4=0 keeps them here: the A/B knob of profiles/r06_attention_ab.txt; read per call so that one process can compare the two)
+    if (!wg_table && (window == 0 || window >= S)) {
+        const char* e4 = getenv("D3D_ATTN_V4");
+        if (!(e4 && e4[0] == '0'))
+            return d3d_flash_attention_v4(qkv, out, B, S, H, head_dim, row_stride, batch_stride, q_off, k_off, v_off, causal, seq_len, cu_seqlens, rope_cos,
+                                          rope_sin, dtype, stream);
+    }
     const float sl2 = 1.4426950408889634f / sqrtf((float)head_dim);
     hipStream_t s = (hipStream_t)stream;
     const uint16_t* q = (const uint16_t*)qkv;

@@ -22,6 +22,7 @@ _lib.register("d3d_set_attention", [vp, vp, i32, i32, i32, i32, vp, vp])
 _lib.register("d3d_flash_attention_v3", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, i32, vp])
 _lib.register("d3d_flash_attention_v3_rope_q", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp])
 _lib.register("d3d_flash_attention_v3_sched", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, vp])
+_lib.register("d3d_flash_attention_v4", [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp])
 _lib.register("d3d_swiglu", [vp, vp, i64, i32, i32, vp])
 _lib.register("d3d_resize_normalize", [vp, vp, i32, i32, i32, i32, vp, vp, vp])
 _lib.register("d3d_decode_attention", [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp])
