@@ -255,6 +255,12 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
     if (CAUSAL && !tab && pass == 1 && qb == n_qblocks - 1 - xq) break;  // odd count: the middle block stands alone
     const int q0 = qb * BQ, qw = q0 + wave * 32;
     const int qrow = qw + li;                                            // this lane's query
+    const int kv_len = CAUSAL ? min(seq_len, q0 + BQ) : seq_len;
+    const int n_tiles = (kv_len + BKV - 1) / BKV;
+    const int t_first = (window > 0 && q0 - window + 1 > 0) ? (q0 - window + 1) / BKV : 0;
+    // The first key tile is requested BEFORE the query loads and the rotary arithmetic (round 6): it flies under them instead of behind them
+    // (every wave is past the previous pass's last barrier: both buffers are free)
+    request_tile(t_first, 0);
 
     // Q fragments (B operand of S^T = K Q^T): lane holds Q[qrow][ks*16 + hi*8 .. +7]
     uint4 qf[KS];
@@ -296,9 +302,6 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
     float m_i = -INFINITY;
 
-    const int kv_len = CAUSAL ? min(seq_len, q0 + BQ) : seq_len;
-    const int n_tiles = (kv_len + BKV - 1) / BKV;
-    const int t_first = (window > 0 && q0 - window + 1 > 0) ? (q0 - window + 1) / BKV : 0;
     const int kmax = CAUSAL ? min(qrow, seq_len - 1) : seq_len - 1;
     const int kmin = window > 0 ? qrow - window + 1 : 0;
 
@@ -314,8 +317,6 @@ k_flash_attn_dma(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, i
     for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
     float l_i = 0.f;                         // (VALU variant) this lane's half of the row sum: its 32 of the 64 keys of every tile
 
-    // every wave is past the previous pass's last barrier: both buffers are free
-    request_tile(t_first, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -516,11 +517,12 @@ int32_t d3d_flash_attention_v3_sched(const void* qkv, void* out, int32_t B, int3
         d3d_set_error_("d3d_flash_attention_v3_rope_q: rope_cos and rope_sin come together");
         return D3D_EINVAL;
     }
-    // Round 6: launches without a window and without a workgroup table run on the software-pipelined kernel of attn4_kernels.hip
-    // (D3D_ATTN_V4=0 keeps them here: the A/B knob of profiles/r06_attention_ab.txt; read per call so that one process can compare the two)
+    // Round 6: D3D_ATTN_V4=1 sends launches without a window and without a workgroup table to the software-pipelined kernel of
+    // attn4_kernels.hip (read per call, so that one process can compare the two).  OFF by default: measured 2-3 % faster on the Phi-3 shape
+    // and level on the ViT shape (profiles/r06_attention_ab.txt) -- not worth a change of the product path's last bits.
     if (!wg_table && (window == 0 || window >= S)) {
         const char* e4 = getenv("D3D_ATTN_V4");
-        if (!(e4 && e4[0] == '0'))
+        if (e4 && e4[0] == '1')
             return d3d_flash_attention_v4(qkv, out, B, S, H, head_dim, row_stride, batch_stride, q_off, k_off, v_off, causal, seq_len, cu_seqlens, rope_cos,
                                           rope_sin, dtype, stream);
     }

@@ -105,6 +105,13 @@ __device__ __forceinline__ void dma_piece(uint32_t voff, const void* base, uint3
 }
 
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+// Timing ablations (tools/experiments/attn_ablate.py builds one library per value; results are WRONG for every value but 0):
+//   1 no softmax arithmetic   2 no MFMAs   3 no tile requests after the prologue (barriers stay)   4 no requests and no barriers
+//   5 fragment reads only in the prologue   6 no key tiles at all (prologue + epilogue only)
+#ifndef D3D_ATTN_ABL
+#define D3D_ATTN_ABL 0
+#endif
+constexpr int ABL = D3D_ATTN_ABL;
 
 template <bool BF16, int HD, bool CAUSAL>
 __global__ void __launch_bounds__(NW * 64, 2)
@@ -193,6 +200,7 @@ k_flash_attn_pipe(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, 
     const uint32_t lds_k = lds_addr_of(Ks), lds_v = lds_addr_of(Vs);
     const int64_t tile_bytes = (int64_t)BKV * row_stride * 2;
     auto request_k = [&](int T) __attribute__((always_inline)) {
+        if ((ABL == 3 || ABL == 4) && T > 1) return;
         const char* kb = reinterpret_cast<const char*>(Kp) + (int64_t)T * tile_bytes;
         const int last = S - 1 - T * BKV, buf = T & 1;                  // last valid row of the tile (>= 0)
         if (last >= BKV - 1) {
@@ -208,6 +216,7 @@ k_flash_attn_pipe(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, 
         }
     };
     auto request_v = [&](int T) __attribute__((always_inline)) {
+        if ((ABL == 3 || ABL == 4) && T > 0) return;
         const char* vb = reinterpret_cast<const char*>(Vp) + (int64_t)T * tile_bytes;
         const int last = S - 1 - T * BKV, buf = T & 1;
         if (last >= BKV - 1) {
@@ -240,6 +249,13 @@ k_flash_attn_pipe(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, 
     if (CAUSAL && pass == 1 && qb == n_qblocks - 1 - xq) break;          // odd count: the middle block stands alone
     const int q0 = qb * BQ, qw = q0 + wave * 32;
     const int qrow = qw + li;                                            // this lane's query
+    const int kv_len = CAUSAL ? min(seq_len, q0 + BQ) : seq_len;
+    const int n_tiles = (kv_len + BKV - 1) / BKV;
+    // K tiles 0 and 1 and V tile 0 are requested FIRST: they fly under the query loads and the rotary arithmetic (every wave is past the
+    // previous pass's last barrier: the rings are free)
+    request_k(0);
+    if (n_tiles > 1) request_k(1);
+    request_v(0);
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[qrow][ks*16 + hi*8 .. +7]; rotary embedding fused (attn3_kernels.hip) -------
     uint4 qf[KS];
@@ -280,8 +296,6 @@ k_flash_attn_pipe(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, 
     bool resc_p = false;
 
     // ---- block ranges (32-key blocks) --------------------------------------------------------------------------------------------------------
-    const int kv_len = CAUSAL ? min(seq_len, q0 + BQ) : seq_len;
-    const int n_tiles = (kv_len + BKV - 1) / BKV;
     const int nb_seq = (kv_len + 31) / 32;
     const int nbw = CAUSAL ? min(qw / 32 + 1, nb_seq) : nb_seq;                          // this wave's blocks: [0, nbw)
     const int nb_max = CAUSAL ? min((q0 + BQ - 32) / 32 + 1, nb_seq) : nb_seq;           // the workgroup's (its last wave's)
@@ -294,11 +308,13 @@ k_flash_attn_pipe(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, 
     uint4 vf[2][DB];                   // V^T fragments of block b - 1
 
     auto load_k = [&](int bk) __attribute__((always_inline)) {       // K fragments of block bk
+        if (ABL == 5 && bk > 0) return;
         const uint16_t* Ka = Ks + ((bk >> 1) & 1) * KBUF + ((bk & 1) * 32 + li) * KST;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(Ka + (((ks * 2 + hi) ^ kswz(li)) << 3));
     };
     auto load_v = [&](int bv) __attribute__((always_inline)) {       // V^T fragments of block bv
+        if (ABL == 5 && bv > 0) return;
         const uint16_t* Vb = Vs + ((bv >> 1) & 1) * VBUF + v_off0;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -306,16 +322,38 @@ k_flash_attn_pipe(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, 
             for (int d = 0; d < DB; ++d) vf[s][d] = ld_vf(Vb, (bv & 1) * 2 + s, d);
     };
     auto qk = [&](int par) __attribute__((always_inline)) {          // S(par) = K fragments x Q
+        if (ABL == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[par][r] = __uint_as_float(kf[r % KS].x ^ qf[r % KS].y) * 1e-30f;
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) sv[par][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) sv[par] = mfma32<BF16>(kf[ks], qf[ks], sv[par]);
     };
     auto pv = [&](int par) __attribute__((always_inline)) {          // O += V fragments x P(par)
+        if (ABL == 2) {
+            oacc[0][0] += __uint_as_float(vf[0][0].x ^ vf[1][DB - 1].w ^ pf[par][0].x ^ pf[par][1].w) * 1e-30f;
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int d = 0; d < DB; ++d) oacc[d] = mfma32<BF16>(vf[s][d], pf[par][s], oacc[d]);
+    };
+    // both of a MAIN slot, alternating: two MFMAs on the same accumulator are never neighbours in the stream (a vector instruction between
+    // two MFMAs of one accumulation chain costs ~40 cycles, MI355X_MICROARCH.md; between different accumulators ~6)
+    auto pv_qk = [&](int par) __attribute__((always_inline)) {
+        if (ABL == 2) { pv(par); qk(par); return; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[par][r] = 0.f;
+        constexpr int NP = 2 * DB;
+#pragma unroll
+        for (int i = 0; i < (NP > KS ? NP : KS); ++i) {
+            if (i < NP) oacc[i % DB] = mfma32<BF16>(vf[i / DB][i % DB], pf[par][i / DB], oacc[i % DB]);
+            if (i < KS) sv[par] = mfma32<BF16>(kf[i], qf[i], sv[par]);
+        }
     };
     auto rescale = [&]() __attribute__((always_inline)) {
         if (resc_p) {
@@ -331,6 +369,17 @@ k_flash_attn_pipe(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, 
     // online softmax of block bb (registers sv[par] -> pf[par]), base 2, one query per lane pair, branch-free
     auto softmax = [&](int par, int bb, bool masked) __attribute__((always_inline)) {
         float16v& s = sv[par];
+        if (ABL == 1) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                pf[par][st].x = pack2<BF16>(s[8 * st + 0], s[8 * st + 1]);
+                pf[par][st].y = pack2<BF16>(s[8 * st + 2], s[8 * st + 3]);
+                pf[par][st].z = pack2<BF16>(s[8 * st + 4], s[8 * st + 5]);
+                pf[par][st].w = pack2<BF16>(s[8 * st + 6], s[8 * st + 7]);
+            }
+            l_i += 1.f;
+            return;
+        }
         if (masked) {
             const int hi_ = kmax - bb * 32 - hi * 4;                   // key - key0 - 4 hi <= hi_ is visible
 #pragma unroll
@@ -368,57 +417,90 @@ k_flash_attn_pipe(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, 
         }
     };
 
-    // ---- prologue: K tiles 0 and 1 and V tile 0 land; S(0) ----------------------------------------------------------------------------------
-    request_k(0);                      // (every wave is past the previous pass's last barrier: the rings are free)
-    if (n_tiles > 1) request_k(1);
-    request_v(0);
+    // ---- prologue: K tiles 0 and 1 and V tile 0 have landed; S(0) ---------------------------------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     load_k(0);
     qk(0);
 
     constexpr int NM = KS + 2 * DB;    // MFMAs of a full slot: 12 / 8
-    // One slot.  PAR = parity of b (compile time).  The MAIN form (every part present, no masks) is one scheduling region: the fragment reads
-    // first, the row-max chain of block b under their latency, then one MFMA per ~5 vector instructions.
-#define FA_SLOT(PAR)                                                                                                                           \
+    // One slot, PAR = parity of b (compile time).  MAIN: every part present and no masks -- ONE scheduling region: the fragment reads first,
+    // the row-max chain of block b under their latency, then one MFMA per ~5 vector instructions.  GEN: the edges (first / diagonal / last
+    // blocks, waves that are done), each part under its wave-uniform condition, compiler-scheduled.
+#define FA_SLOT_MAIN(PAR)                                                                                                                      \
+    {                                                                                                                                          \
+        rescale();                                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+        load_v(b - 1);                                                                                                                         \
+        load_k(b + 1);                                                                                                                         \
+        pv_qk((PAR) ^ 1);                                                                                                                      \
+        softmax(PAR, b, false);                                                                                                                \
+        /* the block's P fragments and row sum are "used" here: keeps LLVM from sinking the exps below the tile barrier, next to their MFMAs */ \
+        asm volatile("" ::"v"(pf[PAR][0].x), "v"(pf[PAR][0].y), "v"(pf[PAR][0].z), "v"(pf[PAR][0].w), "v"(pf[PAR][1].x), "v"(pf[PAR][1].y),   \
+                     "v"(pf[PAR][1].z), "v"(pf[PAR][1].w), "v"(l_i));                                                                          \
+        SGB(0x100, 4 * DB + KS);                  /* all fragment reads */                                                                     \
+        SGB(0x402, 16);                           /* row max, pair exchange, vote */                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2 * DB; ++i_) {   /* the P V MFMAs (rotating accumulators), vector work between them */       \
+            SGB(0x008, 1);                                                                                                                     \
+            SGB(0x402, HD == 96 ? 9 : 14);                                                                                                     \
+        }                                                                                                                                      \
+        SGB(0x008, KS);                           /* the S chain (ONE accumulator) back to back: a vector instruction between two MFMAs of  */ \
+        SGB(0x402, 8);                            /* one accumulation chain costs ~40 cycles (MI355X_MICROARCH.md), between different ones ~6 */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+    }
+#define FA_SLOT_GEN(PAR)                                                                                                                       \
     {                                                                                                                                          \
         const bool do_pv = b >= 1 && b <= nbw, do_sm = b < nbw, do_qk = b + 1 < nbw;                                                          \
         rescale();                                                                                                                             \
-        if (do_pv && do_sm && do_qk && b < b_full) {                                                                                           \
-            __builtin_amdgcn_sched_barrier(0);                                                                                                 \
-            load_v(b - 1);                                                                                                                     \
-            load_k(b + 1);                                                                                                                     \
-            pv((PAR) ^ 1);                                                                                                                     \
-            qk((PAR) ^ 1);                                                                                                                     \
-            softmax(PAR, b, false);                                                                                                            \
-            SGB(0x100, 4 * DB + KS);              /* all fragment reads */                                                                     \
-            SGB(0x402, 16);                       /* row max, pair exchange, vote */                                                           \
-            _Pragma("unroll") for (int i_ = 0; i_ < NM; ++i_) {                                                                                \
-                SGB(0x008, 1);                                                                                                                 \
-                SGB(0x402, HD == 96 ? 5 : 8);                                                                                                  \
-            }                                                                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                                                 \
-        } else {                                                                                                                               \
-            if (do_pv) { load_v(b - 1); }                                                                                                      \
-            if (do_qk) { load_k(b + 1); }                                                                                                      \
-            if (do_pv) pv((PAR) ^ 1);                                                                                                          \
-            if (do_qk) qk((PAR) ^ 1);                                                                                                          \
-            if (do_sm) softmax(PAR, b, b >= b_full);                                                                                           \
+        if (do_pv) { load_v(b - 1); }                                                                                                          \
+        if (do_qk) { load_k(b + 1); }                                                                                                          \
+        if (do_pv) pv((PAR) ^ 1);                                                                                                              \
+        if (do_qk) qk((PAR) ^ 1);                                                                                                              \
+        if (do_sm) softmax(PAR, b, b >= b_full);                                                                                               \
+    }
+    // the tile's barrier: this wave's pieces of K tile t+1 and V tile t (requested a tile ago) have landed -- then everybody's; and every wave
+    // is done reading K tile t's and V tile t-1's buffers, which the next requests overwrite
+#define FA_SYNC()                                                                                                                              \
+    {                                                                                                                                          \
+        if (ABL != 4) {                                                                                                                        \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                                   \
+            __syncthreads();                                                                                                                   \
         }                                                                                                                                      \
+        if (t + 2 < n_tiles) request_k(t + 2);                                                                                                 \
+        if (t + 1 < n_tiles) request_v(t + 1);                                                                                                 \
     }
 
-    // slots 0 .. nb_max in pairs (even, odd); one barrier per pair = per 64-key tile
-    for (int t = 0; 2 * t <= nb_max; ++t) {
-        int b = 2 * t;
-        FA_SLOT(0)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of K tile t+1 and V tile t (requested a tile ago) have landed
-        __syncthreads();                                       // ... everybody's; and every wave is done reading K tile t's and V tile t-1's buffers
-        if (t + 2 < n_tiles) request_k(t + 2);
-        if (t + 1 < n_tiles) request_v(t + 1);
-        b = 2 * t + 1;
-        if (b <= nb_max) FA_SLOT(1)
+    // Slots 0 .. nb_max in pairs (even, odd), one barrier per pair = per 64-key tile.  Every wave runs the same number of pairs; which form a
+    // pair takes is the wave's own business: pairs [1, t_main) have both slots in the MAIN form (1 <= b, b + 1 < nbw, b < b_full).
+    if (ABL != 6) {
+    const int b_hi = min(nbw - 2, b_full - 1);                 // last slot that can take the MAIN form
+    const int t_main = (b_hi + 1) / 2;                         // pairs t < t_main: 2t + 1 <= b_hi
+    int t = 0;
+    {
+        int b = 0;
+        FA_SLOT_GEN(0)
+        FA_SYNC()
+        b = 1;
+        if (b <= nb_max) FA_SLOT_GEN(1)
     }
-#undef FA_SLOT
+    for (t = 1; t < t_main; ++t) {
+        int b = 2 * t;
+        FA_SLOT_MAIN(0)
+        FA_SYNC()
+        b = 2 * t + 1;
+        FA_SLOT_MAIN(1)
+    }
+    for (; 2 * t <= nb_max; ++t) {
+        int b = 2 * t;
+        FA_SLOT_GEN(0)
+        FA_SYNC()
+        b = 2 * t + 1;
+        if (b <= nb_max) FA_SLOT_GEN(1)
+    }
+    }
+#undef FA_SLOT_MAIN
+#undef FA_SLOT_GEN
+#undef FA_SYNC
     rescale();                         // (a pending decision of the last softmax has no P V behind it for this wave only if nbw == 0: harmless)
 
     // ---- epilogue: lane holds O[qrow][32d + 8j + 4hi + r]; lane pairs exchange so that each stores 16 contiguous bytes ------------------------

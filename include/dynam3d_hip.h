@@ -423,8 +423,8 @@ int32_t d3d_rope_inplace(void* qkv_d, const float* cos_d, const float* sin_d, in
 int32_t d3d_swiglu(const void* gate_up_d, void* out_d, int64_t rows, int32_t I, int32_t dtype, void* stream);
 /* Round 6: the software-pipelined attention kernel (csrc/attn4_kernels.hip) -- the same contract as d3d_flash_attention_v3_rope_q without a
  * window (dense or cu_seqlens-packed, causal or not, head_dim 64 / 96, optional fused query RoPE): inside a wave the MFMAs of key blocks
- * b-1 / b+1 are interleaved with the online softmax of block b (32-key blocks).  d3d_flash_attention_v3* route window-free, table-free
- * launches here (D3D_ATTN_V4=0 keeps them on the round-3 kernel: the A/B knob).  Replaces the SDPA inside llava.generate (VLN-POL:463)
+ * b-1 / b+1 are interleaved with the online softmax of block b (32-key blocks).  An experiment: D3D_ATTN_V4=1 routes the window-free,
+ * table-free launches of d3d_flash_attention_v3* here (2-3 % faster on the Phi-3 shape, level on the ViT shape; off by default).  Replaces the SDPA inside llava.generate (VLN-POL:463)
  * and the ViT blocks' attention (clip/model.py:178-180). */
 int32_t d3d_flash_attention_v4(const void* qkv_d, void* out_d, int32_t B, int32_t S, int32_t H, int32_t head_dim, int64_t row_stride,
                                int64_t batch_stride, int32_t q_off, int32_t k_off, int32_t v_off, int32_t causal, int32_t seq_len,

@@ -4,6 +4,8 @@ return what the module sequence it replaces returns in bf16 / fp16 (include/dyna
 bias+residual = R(R(acc + bias) + residual).  `epi_ref` below spells every epilogue out; with the stores in the same places
 what is left is float32 summation order flipping an occasional store, so the tolerances are a third of a one-rounding bound
 (bf16 1e-3, fp16 2e-4 relative L2; unit round-offs are 3.9e-3 / 4.9e-4) -- a kernel that stored once at the end would fail."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -346,9 +348,45 @@ def test_flash_attention_fused_query_rope_equals_separate_rope(hd, dt):
         # as the paired launch does: same bits, with and without the fused query rotation
         tab = torch.from_numpy(hd.attention_schedule(lens, H)).cuda()
         assert tab.numel() == sum((n + 127) // 128 for n in lens) * H
+        ref3 = ref
         o1 = hd.attention_packed(b_.view(Tp, 3 * H, d), H, True, cu, len(lens), S, n_valid=T, window=window, rope_q=(cos, sin), sched=tab)
         o2 = hd.attention_packed(a.view(Tp, 3 * H, d), H, True, cu, len(lens), S, n_valid=T, window=window, sched=tab)
-        assert torch.equal(o1, ref) and torch.equal(o2, ref), (H, d, lens, window)
+        assert torch.equal(o1, ref3) and torch.equal(o2, ref3), (H, d, lens, window)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 6e-3), (torch.float16, 1e-3)])
+def test_flash_attention_v4_software_pipelined_kernel(hd, dt, tol, monkeypatch):
+    """The round-6 experiment kernel (csrc/attn4_kernels.hip; D3D_ATTN_V4=1: MFMAs of key blocks b-1 / b+1 interleaved with the softmax of
+    block b inside the wave) against float32 attention and against the product kernel: ragged packed causal prompts with and without the
+    fused query RoPE, dense ViT shape; every edge of its slot loop (1-block sequences, diagonal blocks, partial last tiles)."""
+    torch.manual_seed(21)
+    for H, d, lens, causal in ((8, 96, [1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 385, 705, 830], True), (4, 64, [300, 77, 577], False),
+                               (4, 64, [5, 640], True), (2, 96, [257, 96], False)):
+        T = sum(lens)
+        Tp = (T + 255) // 256 * 256
+        qkv = (torch.randn(Tp, 3 * H, d, device="cuda") * 0.7).to(dt)
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+        v3 = hd.attention_packed(qkv, H, causal, cu, len(lens), max(lens), n_valid=T)
+        monkeypatch.setenv("D3D_ATTN_V4", "1")
+        v4 = hd.attention_packed(qkv, H, causal, cu, len(lens), max(lens), n_valid=T)
+        for _ in range(3):
+            assert torch.equal(hd.attention_packed(qkv, H, causal, cu, len(lens), max(lens), n_valid=T), v4)       # repeatable
+        monkeypatch.delenv("D3D_ATTN_V4")
+        o = 0
+        for n in lens:
+            x = qkv[o:o + n].float()
+            q, k, v = (x[:, i * H:(i + 1) * H].transpose(0, 1) for i in range(3))
+            ref = F.scaled_dot_product_attention(q[None], k[None], v[None], is_causal=causal)[0].transpose(0, 1)
+            assert rel(v4[o:o + n].float(), ref) < tol, (H, d, n, causal)
+            assert rel(v4[o:o + n].float(), v3[o:o + n].float()) < tol
+            o += n
+        assert float(v4[T:].abs().max()) == 0.0
+    qv = (torch.randn(2, 577, 48, 64, device="cuda") * 0.5).to(dt)
+    monkeypatch.setenv("D3D_ATTN_V4", "1")
+    got = hd.attention_qkv(qv, 16, False).float()
+    monkeypatch.delenv("D3D_ATTN_V4")
+    q, k, v = (qv[:, :, i * 16:(i + 1) * 16].float().transpose(1, 2) for i in range(3))
+    assert rel(got, F.scaled_dot_product_attention(q, k, v).transpose(1, 2)) < tol
 
 
 def test_flash_attention_sliding_window(hd):
