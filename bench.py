@@ -454,6 +454,7 @@ def main():
     TIMER.enabled = False
     counts_timed = D.counts()                                   # dispatch counts of the timed region only
     assert torch.isfinite(lo).all()
+    net.feature_fields.check_numerics()                         # the float32 token-builder GEMMs' status word of the LAST timed update (synchronising: behind the timed region)
     # ---- generation (what the reference's per-step call returns), measured BEHIND the timed region, never part of `value` ----
     decode = None
     if not a.no_decode and rank == 0:

@@ -501,8 +501,8 @@ int32_t d3d_flash_attention_v3_sched(const void* qkv, void* out, int32_t B, int3
                                      int32_t window, const float* rope_cos, const float* rope_sin, const int32_t* wg_table, int32_t n_wg, int32_t dtype,
                                      void* stream) {
     if (B <= 0 || S <= 0) return D3D_OK;
-    if (wg_table && (n_wg <= 0 || H > 4095 || B > 2047)) {
-        d3d_set_error_("d3d_flash_attention_v3_sched: a workgroup table needs n_wg > 0, H <= 4095, B <= 2047");
+    if (wg_table && (n_wg <= 0 || H > 4095 || B > 2047 || (S + 127) / 128 > 256)) {
+        d3d_set_error_("d3d_flash_attention_v3_sched: a workgroup table needs n_wg > 0, H <= 4095, B <= 2047, S <= 32768 (8-bit query-block field)");
         return D3D_EINVAL;
     }
     if ((head_dim != 64 && head_dim != 96) || (row_stride & 7) || (batch_stride & 7) || window < 0 || (window > 0 && !causal)) {

@@ -201,7 +201,8 @@ k_gemm_f32x3(const float* __restrict__ A, const float* __restrict__ W, float* __
     if (status && __any(bad) && lane == 0) atomicOr(status, 1);
 }
 
-// floor(log2(max |row|)) of every row (0 for an all-zero row; clamped to [-100, 100]); a non-finite element ORs bit 1 into `status` and is
+// floor(log2(max |row|)) of every row (0 for an all-zero row; clamped to [-126, 126] = the exponents pow2f(+-e) can build: the scaled maximum
+// of ANY finite row then lies in [2^-23, 4) -- no finite row overflows fp16); a non-finite element ORs bit 1 into `status` and is
 // left out of the maximum.  One wave per row.
 __global__ void __launch_bounds__(256)
 k_row_exponents(const float* __restrict__ X, int M, int K, int64_t ld, int32_t* __restrict__ out, int32_t* __restrict__ status) {
@@ -224,7 +225,7 @@ k_row_exponents(const float* __restrict__ X, int M, int K, int64_t ld, int32_t* 
     if (status && __any(bad) && lane == 0) atomicOr(status, 2);
     if (lane == 0) {
         int e = mx > 0.f ? (int)((__float_as_uint(mx) >> 23) & 0xff) - 127 : 0;      // (a subnormal maximum reads as -127: clamped below)
-        out[row] = max(-100, min(100, e));
+        out[row] = max(-126, min(126, e));
     }
 }
 

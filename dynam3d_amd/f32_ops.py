@@ -102,8 +102,16 @@ class F32Ops:
         key, tag = w.data_ptr(), (w._version, tuple(wp.shape))
         hit = self._wexp.get(key)
         if hit is None or hit[0] != tag or hit[2]() is not w:
+            self._purge(self._wexp)
             hit = self._wexp[key] = (tag, self.row_exponents(wp), weakref.ref(w))
         return hit[1]
+
+    @staticmethod
+    def _purge(cache: dict):
+        """Drop the entries whose source tensor is gone (their padded copies / exponent tensors would otherwise stay on the device across
+        model reloads)."""
+        for k in [k for k, v in cache.items() if v[2]() is None]:
+            del cache[k]
 
     def prep_weight(self, w: torch.Tensor) -> torch.Tensor:
         """(N, K) float32 contiguous; K zero-padded to a multiple of 32 for the MFMA kernels (cached per tensor)."""
@@ -117,6 +125,7 @@ class F32Ops:
         tag = (w._version, N, K)
         hit = self._padded.get(key)
         if hit is None or hit[0] != tag or hit[2]() is not w:
+            self._purge(self._padded)
             wp = torch.zeros((N, (K + self.KPAD - 1) // self.KPAD * self.KPAD), dtype=torch.float32, device=w.device)
             wp[:, :K] = w.detach()
             hit = self._padded[key] = (tag, wp, weakref.ref(w))

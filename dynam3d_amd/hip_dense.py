@@ -356,6 +356,8 @@ class HipDense:
         index mod 8 is the pair's XCD (sequence * H + head) % 8 (an XCD's L2 then serves all query blocks of a head).  numpy int32."""
         import numpy as np
         nqb = [(int(n) + block - 1) // block for n in lens]
+        if max(nqb, default=0) > 256 or n_heads > 4095 or len(lens) > 2047:      # entry = sequence << 20 | head << 8 | query block
+            raise ValueError("attention_schedule: at most 256 query blocks (32 768 tokens) per sequence, 4095 heads, 2047 sequences")
         out = []
         for q in range(max(nqb) - 1, -1, -1):
             buckets = [[] for _ in range(8)]

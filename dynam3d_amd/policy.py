@@ -66,8 +66,19 @@ class SyntheticTokenizer(PromptTokenizer):
     def __init__(self, vocab: int = 32064, add_bos: bool = True):
         self.vocab, self.add_bos = vocab, add_bos
         self._re = re.compile(r"(<\|[a-z]+\|>|<image>|\n|[^\s<]+|<)")
+        self._memo = {}                 # text -> ids of the last few hundred distinct texts (an instruction is encoded once per episode, not per step)
 
     def encode(self, text: str) -> List[int]:
+        hit = self._memo.get(text)
+        if hit is not None:
+            return list(hit)
+        ids = self._encode(text)
+        if len(self._memo) >= 512:
+            self._memo.clear()
+        self._memo[text] = tuple(ids)
+        return ids
+
+    def _encode(self, text: str) -> List[int]:
         out = [self.BOS] if self.add_bos else []
         hi = min(32000, self.vocab) - 100
         for piece in self._re.findall(text):

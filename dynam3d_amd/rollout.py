@@ -112,6 +112,7 @@ def run_closed_loop(net: Dynam3D_VLN, episodes: int, max_steps: int, seed: int, 
         if envs.num_envs == 0:                                                      # VLN-TR:802-804
             ff.delete_feature_fields()
             break
+    ff.check_numerics()           # the float32 token-builder GEMMs' status word is otherwise only looked at by the NEXT update: end of the loop
     return sums, done_n, env_steps, texts
 
 

@@ -362,6 +362,12 @@ class FFTrainer:
             if t is not None:
                 n[: min(S, t.shape[0]), : min(cap, t.shape[1])] = t[: min(S, t.shape[0]), : min(cap, t.shape[1])].to(n.device)
             self.gt_rows = t = n
+        # A row whose instance died in delete_old_features_from_camera_frustum loses its GT id, like the reference's
+        # `global_gt_instance_ids[b][instance_id] = -10000` (PRE-FF:728): dead rows are exactly the tomb-stoned ones (position -10000, both
+        # planners), so the reset is taken from the pool -- otherwise KNN can propose a dead row (fewer than K live instances) whose STALE id
+        # equals the segment's, and the memory would merge into a dead instance where the reference does not merge.  A recycled row gets its
+        # new position and its new id (`new_instances`) before it is read again.
+        t.masked_fill_(pools.inst_pos[: t.shape[0], : t.shape[1], 0] == -10000.0, -10000)
         return t
 
     def new_instances(self, pools, new_slots, new_rows, new_src):
@@ -448,7 +454,8 @@ def pretrain_step(ff, trainer: FFTrainer, optimizer, update_kwargs: dict, clip_v
     torch.nn.utils.clip_grad_value_(params, clip_value)                # PRE-TR:517
     trainer.last_grads = {k: zero(p) for k, p in zip(trainer.model.names, trainer.model.plist)}
     lap("allreduce_scrub_clip")
-    optimizer.step()
+    ff.check_numerics()                                                # a non-finite float32 GEMM of THIS step's update is reported before its
+    optimizer.step()                                                   # gradients reach the weights (one small device-to-host read)
     lap("optimizer")
     sync_weights(ff, trainer.model)
     lap("sync_weights")

@@ -294,7 +294,7 @@ int32_t d3d_gemm_nt_f32(const float* A_d, const float* W_d, float* C_d, const fl
 int32_t d3d_gemm_nt_f32x3(const float* A_d, const float* W_d, float* C_d, const float* bias_d, const float* residual_d, int32_t M, int32_t N,
                           int32_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t epilogue, const int32_t* a_exp_d, const int32_t* w_exp_d,
                           int32_t* status_d, void* stream);
-/* out_d[m] = floor(log2(max |X[m, :]|)) (0 for a zero row, clamped to +-100); a non-finite element ORs bit 1 into status_d (nullable) and
+/* out_d[m] = floor(log2(max |X[m, :]|)) (0 for a zero row, clamped to +-126); a non-finite element ORs bit 1 into status_d (nullable) and
  * is left out of the maximum.  X (M, K) float32, K % 4 == 0, ld % 4 == 0. */
 int32_t d3d_row_exponents(const float* X_d, int32_t M, int32_t K, int64_t ld, int32_t* out_d, int32_t* status_d, void* stream);
 /* y = [gelu](x W^T + b) for 1 <= K <= 8 (geometry inputs of the position-embedding MLPs; W (N,K) contiguous) */

@@ -287,6 +287,40 @@ def g10_patch_segm():
     print("g10 ok", [int(cases[f"segm_{i}"].max()) + 1 for i in range(len(specs))])
 
 
+def g10b_patch_segm_batch():
+    """a6 at the step's own size (round 6): ONE call of the reference's `get_patch_segm` (VLN-FF:399-430) on B * V = 8 images
+    of 336 x 336 with FastSAM-shaped outputs injected -- 40 to 120 overlapping masks per image, one image whose segmenter call fails (the
+    `except` branch, VLN-FF:424-426: an all-zero map).  The masks are stored bit-packed (inputs are data); the expected label maps are the
+    reference function's return value."""
+    m = rh.load_ref_module("vln")
+    sys.argv = ["x"]
+    F = m.Feature_Fields(batch_size=1, device="cpu")
+    rng = np.random.default_rng(1010)
+    queue = []
+
+    class Prompt:
+        def __init__(self, *a, **k):
+            pass
+
+        def everything_prompt(self):
+            mk = queue.pop(0)
+            if mk is None:
+                raise RuntimeError("no masks")
+            return torch.from_numpy(mk)
+
+    m.FastSAMPrompt = Prompt
+    F.FastSAM = lambda *a, **k: None
+    counts = [40, 64, 90, 0, 41, 120, 55, 48]
+    H = W = 336
+    stacks = [synth_masks(rng, n, H, W) if n else None for n in counts]
+    queue.extend(stacks)
+    out = m.Feature_Fields.get_patch_segm(F, [np.zeros((H, W, 3), np.uint8)] * len(counts))          # (8, 1, 24, 24) int64
+    allm = np.concatenate([s.astype(np.uint8) for s in stacks if s is not None])
+    np.savez_compressed(os.path.join(OUT, "g10b_patch_segm_batch.npz"), counts=np.asarray(counts, np.int64), H=np.int64(H), W=np.int64(W),
+                        masks_packed=np.packbits(allm.reshape(-1)), segm=out.numpy())
+    print("g10b ok", [int(out[i].max()) + 1 for i in range(len(counts))])
+
+
 def g7_text_to_action():
     """Executes the reference's own `convert_text_to_action` (VLN-POL:472-506): the module cannot
     be imported (habitat/gym/cv2/peft), so the single FunctionDef is located with `ast` and
@@ -361,6 +395,6 @@ def g20_gt_text():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g7"]
     torch.set_num_threads(8)
-    fns = {"g1": g1_unproject, "g2": g2_frustum, "g2b": g2b_frustum_pinhole, "g3": g3_knn, "g4": g4_trajectories, "g7": g7_text_to_action, "g10": g10_patch_segm, "g20": g20_gt_text}
+    fns = {"g1": g1_unproject, "g2": g2_frustum, "g2b": g2b_frustum_pinhole, "g3": g3_knn, "g4": g4_trajectories, "g7": g7_text_to_action, "g10": g10_patch_segm, "g10b": g10b_patch_segm_batch, "g20": g20_gt_text}
     for w in which:
         fns[w]()

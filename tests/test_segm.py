@@ -56,6 +56,46 @@ def test_patch_segm_kernel_matches_reference_golden():
         assert np.array_equal(segm[i].cpu().numpy(), ref) and int(n_seg[i]) == int(ref.max()) + 1
 
 
+def _batch_case():
+    """g10b: ONE call of the reference's get_patch_segm on B * V = 8 images of 336 x 336, 40-120 overlapping FastSAM-shaped masks each, one
+    image whose segmenter call fails (VLN-FF:424-426)."""
+    g = load("g10b_patch_segm_batch.npz")
+    counts, H, W = g["counts"].tolist(), int(g["H"]), int(g["W"])
+    allm = np.unpackbits(g["masks_packed"])[: sum(counts) * H * W].reshape(sum(counts), H, W)
+    return counts, allm, g["segm"]
+
+
+def test_oracle_patch_segm_matches_reference_golden_batch_of_8():
+    counts, allm, ref = _batch_case()
+    off = np.concatenate([[0], np.cumsum(counts)])
+    for i, n in enumerate(counts):
+        assert np.array_equal(G.patch_segm_from_masks(allm[off[i]:off[i + 1]].reshape(n, *allm.shape[1:])), ref[i]), i
+    assert not ref[3].any()                                           # the failed image: the reference's `except` branch returns zeros
+
+
+@pytest.mark.gpu
+def test_patch_segm_kernel_batch_of_8_at_336_matches_reference_golden():
+    """SURVEY.md 8 f-3 contract at the step's own size, on the GPU: the adapter's whole batch (8 images, 458 masks of 336 x 336, one image
+    without masks) in ONE d3d_patch_segm_from_masks launch against the label maps the reference's own function returned."""
+    from dynam3d_amd.ops import HipOps
+    from dynam3d_amd.segm import MaskSegmenter
+    counts, allm, ref = _batch_case()
+    off = np.concatenate([[0], np.cumsum(counts)]).tolist()
+    ops = HipOps()
+    segm, n_seg = ops.patch_segm_from_masks(torch.from_numpy(allm).cuda().contiguous(), off, 24, 24)
+    assert np.array_equal(segm.cpu().numpy(), ref)
+    assert n_seg.cpu().tolist() == [int(ref[i].max()) + 1 for i in range(len(counts))]
+    # ... and through the adapter object the policy holds (a segmenter callable per image; the failing one raises like FastSAM's wrapper)
+    stacks = {i: allm[off[i]:off[i + 1]].astype(np.float32) for i in range(len(counts))}
+
+    def fastsam_like(i):
+        if counts[i] == 0:
+            raise RuntimeError("FastSAM error")
+        return stacks[i]
+    out = MaskSegmenter(fastsam_like, ops, device="cuda")(list(range(len(counts))))
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
 def test_feature_fields_uses_configured_segmenter():
     """`update_feature_fields(..., batch_image)` without an explicit patch_segm goes through `get_patch_segm` (VLN-FF:504-506) ->
     the configured MaskSegmenter; the result must equal the run that was handed the same labels directly."""

@@ -220,3 +220,27 @@ def test_pretrain_step_on_hip_kernels_matches_float64_oracle():
           f"gradient relative L2 error within 5e-4 over {len(b1)} parameter tensors")
     for k, v in model.named_state().items():
         assert torch.equal(ff.dense.w[k], v)
+
+
+def test_dead_instance_rows_lose_their_gt_id():
+    """PRE-FF:728: an instance that dies in delete_old_features_from_camera_frustum loses its ground-truth id (-10000), so a proposal that
+    lands on the dead row (fewer than K live instances) can never match a segment's GT id and is never merged into.  The product keeps the
+    GT table next to the instance pool and takes the reset from the pool's tomb-stones."""
+    from types import SimpleNamespace
+    from dynam3d_amd.train_ff import FFTrainer
+    tr = FFTrainer.__new__(FFTrainer)
+    tr.gt_rows = None
+    pools = SimpleNamespace(inst_pos=torch.zeros((2, 6, 3)))
+    t = tr._gt_rows(pools)
+    assert t.shape == (2, 6) and bool((t == -1).all())
+    t[0, :4] = torch.tensor([7, 3, 7, 9])
+    t[1, :2] = torch.tensor([3, 3])
+    pools.inst_pos[0, 2] = -10000.0                       # instance row 2 of slot 0 dies (fill_rows / d3d_ffdev_apply_hits tomb-stone it)
+    pools.inst_pos[1, 0] = -10000.0
+    t = tr._gt_rows(pools)
+    assert t[0].tolist() == [7, 3, -10000, 9, -1, -1] and t[1].tolist() == [-10000, 3, -1, -1, -1, -1]
+    seg_gt = torch.tensor([7, 3])                         # two segments whose proposals land on (slot 0, row 2) and (slot 1, row 0): dead rows
+    assert not bool((t[torch.tensor([0, 1]), torch.tensor([2, 0])] == seg_gt).any())
+    pools.inst_pos[0, 2] = torch.tensor([1.0, 2.0, 3.0])  # the row is recycled: new position, new id
+    tr._gt_rows(pools)[0, 2] = 11
+    assert tr._gt_rows(pools)[0].tolist() == [7, 3, 11, 9, -1, -1]
