@@ -231,46 +231,8 @@ class Feature_Fields(RefreshOnChange):
                                            self.args.input_vfov, self.device)
         return self._cam
 
-    # Small host -> device uploads (index lists, poses, counts: ~20 per step in the VLN update, ~250 in a pre-training step) go through a
-    # PINNED staging ring: `.to(device, non_blocking=True)` from pageable numpy memory is a synchronous staging copy of ~15 us of host time
-    # each, on the update's latency chain; from pinned memory it is one asynchronous enqueue.  The ring is large (4 MiB per half) and
-    # a half is only reused behind an event recorded when it was left, so a staged array is never overwritten before its copy has run.
-    class _PinnedRing:
-        HALF = 4 << 20
-
-        def __init__(self):
-            self.buf = torch.empty(2 * self.HALF, dtype=torch.uint8).pin_memory()
-            self.half, self.off, self.events = 0, 0, [None, None]
-
-        def stage(self, a: np.ndarray) -> torch.Tensor:
-            n = a.nbytes
-            if n > self.HALF // 4:
-                return torch.from_numpy(a)                                 # large arrays: the ordinary pageable path
-            need = (n + 63) // 64 * 64
-            if self.off + need > self.HALF:
-                ev = torch.cuda.Event()
-                ev.record()
-                self.events[self.half] = ev
-                self.half ^= 1
-                self.off = 0
-                if self.events[self.half] is not None:
-                    self.events[self.half].synchronize()
-            lo = self.half * self.HALF + self.off
-            self.off += need
-            t = self.buf[lo:lo + n].view(torch.from_numpy(a[:0].reshape(-1)).dtype).view(a.shape)
-            t.numpy()[...] = a
-            return t
-
-    def _stage(self, a: np.ndarray) -> torch.Tensor:
-        if self.device.type != "cuda" or a.size == 0:
-            return torch.from_numpy(a)
-        ring = getattr(self, "_ring", None)
-        if ring is None:
-            ring = self._ring = Feature_Fields._PinnedRing()
-        return ring.stage(a)
-
     def _i32(self, a) -> torch.Tensor:
-        return self._stage(np.ascontiguousarray(a, np.int32)).to(self.device, non_blocking=True)
+        return torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(self.device, non_blocking=True)
 
     def _i32_many(self, *arrays):
         """Several int32 index arrays in ONE host-to-device copy (every small upload is ~15 us of host time on the update's latency
@@ -283,11 +245,11 @@ class Feature_Fields(RefreshOnChange):
         buf = np.zeros(max(n, 4), np.int32)
         for a, o in zip(arrs, offs):
             buf[o:o + a.size] = a
-        dev = self._stage(buf).to(self.device, non_blocking=True)
+        dev = torch.from_numpy(buf).to(self.device, non_blocking=True)
         return [dev[o:o + a.size] for a, o in zip(arrs, offs)]
 
     def _f32(self, a) -> torch.Tensor:
-        return self._stage(np.ascontiguousarray(a, np.float32)).to(self.device, non_blocking=True)
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device, non_blocking=True)
 
     def _dev(self, x, dtype=torch.float32) -> torch.Tensor:
         if isinstance(x, np.ndarray):
