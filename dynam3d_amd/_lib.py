@@ -69,6 +69,8 @@ def load() -> C.CDLL:
         raise NativeLibraryMissing(
             f"{LIB_PATH} not found -- build it with `python -m dynam3d_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback for the product path.")
+    import torch  # noqa: F401  -- FIRST: torch brings its own libamdhip64; a process that loaded this library (and with it /opt/rocm's
+    #                  runtime) before torch ends up with two HIP runtimes, and the one behind this library sees no device (hipErrorNoDevice)
     lib = C.CDLL(LIB_PATH)
     lib.d3d_last_error.restype = C.c_char_p
     for name, argtypes in SIGNATURES.items():
