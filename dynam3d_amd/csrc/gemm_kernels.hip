@@ -218,7 +218,15 @@ constexpr int TM = 256, TN = 256, T_THREADS = 512;
 // that would not fill a round, each cut into `splits` K-slices so that the partial last round lasts 1/splits of a tile
 // instead of a whole one.  Every slice writes its fp32 accumulators to the workspace and leaves; k_splitk_fixup (the next launch)
 // sums the slices in slice order -- deterministic -- and runs the fused epilogue.
-template <bool BF16, int EPI, bool KFULL, bool SPLIT, int DMAV = 0>
+// PERSIST (round 6 experiment, unsplit interleaved loop only): the grid is one workgroup per CU and every workgroup WALKS the tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... -- the tiles the dispatcher would have handed that CU round by round (same XCD: gridDim.x % 8 == 0),
+// computed exactly as before (bit-identical results) -- so that a finished tile is followed by the next one without a workgroup turnover.
+// MEASURED (profiles/r06_gemm_persistent_ab.txt): +0.3 ... +1.1 % on the step's multi-round shapes (gate_up -5 us, qkv -1 ... -2.5 us per
+// launch): the turnover is not where the time is, but the walk is free and bit-identical -- ON for grids of more than one round
+// (D3D_GEMM_PERSIST=0: the dispatcher's rounds, the A/B knob).  A variant that also requested the next tile's first K tile under the SwiGLU epilogue (which parks only the
+// first K-tile buffer) was 1-2 % SLOWER than turnover (its wait for the prefetched pieces stalls the epilogue or drags the output stores'
+// completion onto the tile's critical path) and was removed.
+template <bool BF16, int EPI, bool KFULL, bool SPLIT, int DMAV = 0, bool PERSIST = false>
 __global__ void __launch_bounds__(T_THREADS, 2)
 k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* __restrict__ C,
               const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, int M, int N, int K, int64_t lda,
@@ -236,7 +244,9 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
         tr = __builtin_amdgcn_s_memrealtime();
     }
     const int nwg = SPLIT ? dp_tiles : tiles_m * tiles_n;
-    int wg = blockIdx.x;
+    static_assert(!PERSIST || (!SPLIT && (DMAV & 15) == 2 && (DMAV & 16) == 0 && EPI != EPI_LRELU_BWD), "PERSIST: the unsplit interleaved loop");
+  for (int lin_wg = blockIdx.x; lin_wg < (PERSIST ? nwg : (int)blockIdx.x + 1); lin_wg += gridDim.x) {
+    int wg = lin_wg;
     int kb = 0, ke = nk, slice = 0, tail_idx = -1;
     if (!SPLIT || wg < nwg) {
         const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
@@ -484,6 +494,10 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
         __builtin_amdgcn_s_barrier();              // every wave is done reading the K-tile buffers
         epilogue_transposed<BF16, EPI, 8>(acc, reinterpret_cast<char*>(smem) + wave * (128 * (EPI == EPI_SWIGLU ? 64 : 128)), lane,
                                           row0 + grp * 128, col0 + wn * 64, M, C, bias, residual, ldc);
+        if constexpr (PERSIST) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // every wave has read its parked sub-tile back: the next tile's LDS-DMA may overwrite the buffers
+        }
     }
     if constexpr (TIMED) {
         tk[3] = __builtin_readcyclecounter();
@@ -493,6 +507,7 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
             o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3]; o[4] = tr; o[5] = tr1;
         }
     }
+  }   // tile walk (one trip unless PERSIST)
 }
 
 // K-loop of the 256 x 256 kernels picked by d3d_gemm_nt: the interleaved loop (tile codes 260 / 264) unless D3D_GEMM_LOOP=0 asks for
@@ -501,6 +516,8 @@ inline bool gemm_loop_interleaved() {
     static const bool v = [] { const char* e = getenv("D3D_GEMM_LOOP"); return !(e && e[0] == '0'); }();
     return v;
 }
+
+int cu_count();
 
 inline int tile_group_m() {
     static const int gm = [] {
@@ -524,6 +541,23 @@ int32_t launch256(const void* A, const void* W, void* C, const void* bias, const
     D3D_HIP(attr_err);
     float* dbg = nullptr;
     if constexpr ((DMAV & 16) != 0) D3D_HIP(hipMalloc(&dbg, (size_t)tm * tn * 6 * sizeof(unsigned long long)));
+    if constexpr (DMAV == 2 && KFULL && EPI != EPI_LRELU_BWD) {
+        // one workgroup per CU walking the tiles (D3D_GEMM_PERSIST=0, read per call, keeps the dispatcher's rounds: the A/B knob of
+        // profiles/r06_gemm_persistent_ab.txt)
+        const char* ep = getenv("D3D_GEMM_PERSIST");
+        const int P = cu_count();
+        if (!(ep && ep[0] == '0') && tm * tn > P && (P & 7) == 0) {
+            static std::once_flag attr_once_p;
+            static hipError_t attr_err_p = hipSuccess;
+            std::call_once(attr_once_p, [&] {
+                attr_err_p = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, true, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            });
+            D3D_HIP(attr_err_p);
+            hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, true, false, 2, true>), dim3(P), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W,
+                               (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, tile_group_m(), dbg);
+            D3D_LAUNCH_CHECK();
+        }
+    }
     hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL, false, DMAV>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W,
                        (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, tile_group_m(), dbg);
     if constexpr ((DMAV & 16) != 0) {
