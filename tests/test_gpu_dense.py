@@ -490,38 +490,3 @@ def test_vit_shape_attention_five_wave_workgroups(hd, dt, tol, monkeypatch):
     assert rel(out5.float(), ref) < tol
     # a shape where 160-row blocks do not save a round keeps the 4-wave kernel (nothing to compare, just runs): 2 images
     assert torch.isfinite(hd.attention_qkv(qkv[:2].contiguous(), H, False).float()).all()
-
-
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_gemm_persistent_tile_walk_is_bit_identical(hd, dt, monkeypatch):
-    """Round 6: grids of more than one round run as one workgroup per CU walking its tiles (k_gemm_nt_256<..., PERSIST>); D3D_GEMM_PERSIST=0
-    (read per call) keeps the dispatcher's rounds.  Same tiles, same arithmetic: bit-identical, for every epilogue of the multi-round
-    launches, a row count that is not a multiple of the tile and a tile count that is not a multiple of 8."""
-    from dynam3d_amd.hip_dense import interleave_gate_up
-    torch.manual_seed(31)
-    for M, N, K, kind in ((6656, 9216, 3072, "none"), (5000, 4096, 1024, "bias_res"), (6144, 8192, 512, "swiglu"), (4360, 4352, 256, "quick_gelu")):
-        x = (torch.randn(M, K, device="cuda") * 0.5).to(dt)
-        w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt)
-        b = torch.randn(N, device="cuda").to(dt)
-        r = torch.randn(M, N, device="cuda").to(dt)
-        if kind == "swiglu":
-            wi = interleave_gate_up(w)
-            fn = lambda: hd.linear_swiglu(x, wi)
-        elif kind == "bias_res":
-            fn = lambda: hd.linear(x, w, b, None, r)
-        elif kind == "quick_gelu":
-            fn = lambda: hd.linear(x, w, b, "quick_gelu")
-        else:
-            fn = lambda: hd.linear(x, w, None, None)
-        hd.TILE = 260
-        try:
-            walk = fn().clone()
-            monkeypatch.setenv("D3D_GEMM_PERSIST", "0")
-            rounds = fn().clone()
-            monkeypatch.delenv("D3D_GEMM_PERSIST")
-        finally:
-            hd.TILE = 0
-        assert torch.equal(walk, rounds), (M, N, K, kind)
-        ref = x.float() @ w.float().t()
-        if kind == "none":
-            assert rel(walk.float(), ref) < 1e-2

@@ -1,4 +1,4 @@
-"""A/B of the 256 x 256 GEMM with workgroup turnover (default) against the persistent tile walk (the default since round 6; D3D_GEMM_PERSIST=0, read per call, = turnover): the
+"""(Needs tools/experiments/gemm_persistent_walk/gemm_kernels.hip built into the library.)  A/B of the 256 x 256 GEMM with workgroup turnover (default) against the persistent tile walk (D3D_GEMM_PERSIST=1, read per call): the
 step's multi-round shapes, interleaved rounds in one process, bit-identity of the results."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -218,10 +218,19 @@ constexpr int TM = 256, TN = 256, T_THREADS = 512;
 // that would not fill a round, each cut into `splits` K-slices so that the partial last round lasts 1/splits of a tile
 // instead of a whole one.  Every slice writes its fp32 accumulators to the workspace and leaves; k_splitk_fixup (the next launch)
 // sums the slices in slice order -- deterministic -- and runs the fused epilogue.
-// (Round 6 tried a persistent data-parallel tile walk on top of this kernel: +0.3 ... 1.1 %, but it spills -- parked with its evidence
-//  under tools/experiments/gemm_persistent_walk/.  This kernel runs at the 256-register budget with ZERO spills in the step's
-//  instantiations; tests/test_kernel_resources.py keeps it that way.)
-template <bool BF16, int EPI, bool KFULL, bool SPLIT, int DMAV = 0>
+// PERSIST (round 6 experiment, unsplit interleaved loop only; OPT-IN: D3D_GEMM_PERSIST=1): the grid is one workgroup per CU and every
+// workgroup WALKS the tiles blockIdx.x, blockIdx.x + gridDim.x, ... -- the tiles the dispatcher would have handed that CU round by round
+// (same XCD: gridDim.x % 8 == 0), computed exactly as before (bit-identical results) -- so that a finished tile is followed by the next one
+// without a workgroup turnover.  MEASURED (profiles/r06_gemm_persistent_ab.txt): +0.3 ... +1.1 % on the step's multi-round shapes (gate_up
+// -5 us, qkv -1 ... -2.5 us per launch; -0.1 ms on the step): the turnover is not where the time is.  A variant that also requested the
+// next tile's first K tile under the SwiGLU epilogue (which parks only the first K-tile buffer) was 1-2 % SLOWER than turnover and was removed.
+// WHY IT IS OFF BY DEFAULT (profiles/r06_gemm_scratch_regression.txt): its instantiations keep the walk's state alive across the back
+// edge and spill 6-49 VGPRs to scratch at the 256-register budget.  The first version of this change wrapped the body of EVERY
+// instantiation in a (one-trip) `for`, which made hipcc spill 9-56 VGPRs in the production kernels too -- and that build gave wrong
+// logits or a memory access fault in about every second process of tests/test_gpu_full_step.py (bisected to this file; independent of
+// D3D_GEMM_PERSIST and of the runtime's scratch settings).  The body is a lambda now: the production instantiations are back to round
+// 5's code (no spills; tests/test_kernel_resources.py holds them to it), and the spilling walk is not worth 0.2 % of a step.
+template <bool BF16, int EPI, bool KFULL, bool SPLIT, int DMAV = 0, bool PERSIST = false>
 __global__ void __launch_bounds__(T_THREADS, 2)
 k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, uint16_t* __restrict__ C,
               const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, int M, int N, int K, int64_t lda,
@@ -239,7 +248,11 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
         tr = __builtin_amdgcn_s_memrealtime();
     }
     const int nwg = SPLIT ? dp_tiles : tiles_m * tiles_n;
-    int wg = blockIdx.x;
+    static_assert(!PERSIST || (!SPLIT && (DMAV & 15) == 2 && (DMAV & 16) == 0 && EPI != EPI_LRELU_BWD), "PERSIST: the unsplit interleaved loop");
+  // ONE tile.  The body is a lambda so that only the PERSIST instantiations carry a loop: wrapped in a (one-trip) `for`, every other
+  // instantiation kept values alive across a back edge it never takes and SPILLED 9-52 VGPRs to scratch (round 5: none).
+  auto one_tile = [&](const int lin_wg) __attribute__((always_inline)) {
+    int wg = lin_wg;
     int kb = 0, ke = nk, slice = 0, tail_idx = -1;
     if (!SPLIT || wg < nwg) {
         const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
@@ -487,6 +500,10 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
         __builtin_amdgcn_s_barrier();              // every wave is done reading the K-tile buffers
         epilogue_transposed<BF16, EPI, 8>(acc, reinterpret_cast<char*>(smem) + wave * (128 * (EPI == EPI_SWIGLU ? 64 : 128)), lane,
                                           row0 + grp * 128, col0 + wn * 64, M, C, bias, residual, ldc);
+        if constexpr (PERSIST) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // every wave has read its parked sub-tile back: the next tile's LDS-DMA may overwrite the buffers
+        }
     }
     if constexpr (TIMED) {
         tk[3] = __builtin_readcyclecounter();
@@ -496,6 +513,12 @@ k_gemm_nt_256(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, ui
             o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3]; o[4] = tr; o[5] = tr1;
         }
     }
+  };
+  if constexpr (PERSIST) {
+      for (int lin_wg = blockIdx.x; lin_wg < nwg; lin_wg += gridDim.x) one_tile(lin_wg);
+  } else {
+      one_tile(blockIdx.x);
+  }
 }
 
 // K-loop of the 256 x 256 kernels picked by d3d_gemm_nt: the interleaved loop (tile codes 260 / 264) unless D3D_GEMM_LOOP=0 asks for
@@ -504,6 +527,8 @@ inline bool gemm_loop_interleaved() {
     static const bool v = [] { const char* e = getenv("D3D_GEMM_LOOP"); return !(e && e[0] == '0'); }();
     return v;
 }
+
+int cu_count();
 
 inline int tile_group_m() {
     static const int gm = [] {
@@ -527,6 +552,23 @@ int32_t launch256(const void* A, const void* W, void* C, const void* bias, const
     D3D_HIP(attr_err);
     float* dbg = nullptr;
     if constexpr ((DMAV & 16) != 0) D3D_HIP(hipMalloc(&dbg, (size_t)tm * tn * 6 * sizeof(unsigned long long)));
+    if constexpr (DMAV == 2 && KFULL && EPI != EPI_LRELU_BWD) {
+        // D3D_GEMM_PERSIST=1 (read per call; default: the dispatcher's rounds): one workgroup per CU walking the tiles -- the A/B knob of
+        // profiles/r06_gemm_persistent_ab.txt; opt-in because these instantiations spill to scratch (see the kernel's header)
+        const char* ep = getenv("D3D_GEMM_PERSIST");
+        const int P = cu_count();
+        if (ep && ep[0] == '1' && tm * tn > P && (P & 7) == 0) {
+            static std::once_flag attr_once_p;
+            static hipError_t attr_err_p = hipSuccess;
+            std::call_once(attr_once_p, [&] {
+                attr_err_p = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt_256<BF16, EPI, true, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            });
+            D3D_HIP(attr_err_p);
+            hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, true, false, 2, true>), dim3(P), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W,
+                               (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, tile_group_m(), dbg);
+            D3D_LAUNCH_CHECK();
+        }
+    }
     hipLaunchKernelGGL((k_gemm_nt_256<BF16, EPI, KFULL, false, DMAV>), dim3(tm * tn), dim3(T_THREADS), sh, s, (const uint16_t*)A, (const uint16_t*)W,
                        (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, tm, tn, 0, tile_group_m(), dbg);
     if constexpr ((DMAV & 16) != 0) {
