@@ -889,6 +889,9 @@ int32_t launch_skinny(const void* A, const void* W, void* C, const void* bias, c
     // 16-row x 64-byte wave loads are not the guide's 1 KiB LDS-DMA stream).  D3D_SKINNY_NT=1 selects them (read per call: bench_decode.py).
     const char* nte = getenv("D3D_SKINNY_NT");
     const bool nt = nte && nte[0] == '1';
+    // (Round 6 tried a deep-prefetch version -- a wave requests its whole K range, 8-16 steps, before the activation rows are staged: bit-identical,
+    //  NOT faster (qkv 21.3 -> 20.6 us, down_proj 15.5 -> 18.3 us, token 3.10 -> 3.20 ms): the per-launch cost here is fixed ramp / prologue /
+    //  drain, ~8 us, not the depth of the stream -- whose marginal rate is already 6.2 TB/s.  tools/experiments/skinny_deep/.)
 #define D3D_SKINNY_LAUNCH(HALFV, NTV)                                                                                                    \
     hipLaunchKernelGGL((k_gemm_skinny<BF16, EPI, HALFV, NORM, NTV>), dim3(ntiles), dim3(nwv * 64), sh, s, (const uint16_t*)A, (const uint16_t*)W, \
                        (uint16_t*)C, (const uint16_t*)bias, (const uint16_t*)res, M, N, K, lda, ldw, ldc, nw, eps)
