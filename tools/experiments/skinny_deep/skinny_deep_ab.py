@@ -2,7 +2,7 @@
 read per call): bit-identity of the results and us / TB/s per launch on the five projections of a Phi-3 layer at 8 rows.  Weights rotate over
 `COPIES` distinct tensors per shape so that no launch finds its weights in the Infinity Cache."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 from dynam3d_amd import hip_dense as H
 from dynam3d_amd.hip_dense import interleave_gate_up
@@ -11,7 +11,7 @@ hd = H.HipDense()
 torch.manual_seed(3)
 dt = torch.bfloat16
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-COPIES = 6
+COPIES = int(os.environ.get("COPIES", "6"))
 shapes = [("qkv  (norm)", 9216, 3072, "norm"), ("o_proj (res)", 3072, 3072, "res"), ("gate_up (norm, SwiGLU)", 16384, 3072, "norm_swiglu"),
           ("down (res)", 3072, 8192, "res"), ("lm_head (norm)", 32064, 3072, "norm")]
 for name, N, K, kind in shapes:
