@@ -40,7 +40,14 @@ def test_no_kernel_uses_scratch_beyond_its_budget(table):
     over = []
     for r in table:
         fam = r["short"].split("<")[0]
-        if r["scratch"] > BUDGET.get(fam, 0) or r["dynamic_stack"]:
+        budget = BUDGET.get(fam, 0)
+        if fam == "k_flash_attn_dma" and not r["short"].startswith(("k_flash_attn_dma<0,96,1,4", "k_flash_attn_dma<1,96,1,4")):
+            budget = 0                                          # only the Phi-3 prefill instantiation (head_dim 96, causal, 4 waves) has its 4 registers
+        if fam == "k_gemm_nt_256":
+            a = r["short"][len("k_gemm_nt_256<"):-1].split(",")
+            if a[1] in STEP_GEMM_EPI and a[2] == "1" and a[4] == "2":
+                budget = 0                                      # the step's own instantiations: none
+        if r["scratch"] > budget or r["dynamic_stack"]:
             over.append((r["short"], r["scratch"], r["spills"]))
     assert not over, "kernels with scratch beyond the budget (a spilling build -- look at the last change of that kernel): " + repr(over)
 
